@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the GPU ray-cast path on the 1M-triangle BVH scene (BASELINE config 2).
+
+A step is one pass of the hot path over one batch: a full 1920x1080 primary-ray frame (ray generation +
+BVH traversal + ray/triangle intersection + closest hit -> 16-byte hit records) against the 1 000 000-triangle
+terrain, inputs (scene, BVH) resident in HBM, outputs written to HBM.  With N > 1 every rank renders its own
+frame of the sequence (frame f -> rank f mod N, camera moved per frame; BVH replicated) and the hit buffers are
+gathered to rank 0 with RCCL inside the timed region: weak scaling.
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (k_render_primary) against HBM peak using
+ALGORITHMIC bytes (nodes visited x 64 B + triangles tested x 72 B + 16 B hit record per ray, counted by the
+kernel's counting build on the same frame); `cpu_baseline` is the oracle (C++ restatement of the reference
+renderer, kind "port") timed on this host's cores on the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+WIDTH, HEIGHT = 1920, 1080
+GRID = (1000, 500)             # quads -> 1 000 000 triangles
+SEED = 7
+LOCAL_SCALE = 100.0
+
+
+def frame_view(rtg, frame):
+    """Camera of frame `frame` of the sequence: the default view dollying slowly sideways."""
+    return rtg.make_view(orig=(0.002 * frame, 0.0, 1.0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--traversal", type=int, default=-1, help="0 short stack, 1 threaded, -1 library default")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--grid", type=str, default=None, help="NXxNY quads (default 1000x500)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import rtg
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    nx, ny = GRID if args.grid is None else tuple(int(v) for v in args.grid.lower().split("x"))
+    t0 = time.time()
+    tris = rtg.heightfield(nx, ny, SEED, LOCAL_SCALE)
+    bvh = rtg.HostBvh(tris)                       # host-side BvhForest::subdivide + Bvh::new
+    build_s = time.time() - t0
+    ctx = rtg.Context(local_rank)
+    if args.traversal >= 0:
+        ctx.set_option("traversal", args.traversal)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)            # kernels and torch events share one stream
+    mesh = ctx.mesh(bvh)
+    obj = rtg.mesh_object(mesh, rtg.material((0.8, 0.7, 0.6)), rtg.transform(1.0 / LOCAL_SCALE))
+    scene = ctx.scene([obj])
+
+    n_rays = WIDTH * HEIGHT
+    tile = (0, 0, WIDTH, HEIGHT)
+    hits = torch.empty(n_rays * 16, dtype=torch.uint8, device=dev)
+    gathered = [torch.empty_like(hits) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step(i, ev=None):
+        frame = i * world + rank
+        if ev is not None:
+            ev[0].record(stream)
+        scene.render_primary_raw(frame_view(rtg, frame), WIDTH, HEIGHT, tile, hits.data_ptr())
+        if ev is not None:
+            ev[1].record(stream)
+        if world > 1:
+            dist.gather(hits, gathered, dst=0)
+
+    for i in range(args.warmup):
+        step(i)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, events[i])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+    if rank == 0:
+        # algorithmic bytes of one launch, from the kernel's own counting build on frame 0
+        ctr = torch.empty(n_rays * 2, dtype=torch.int32, device=dev)
+        scene.render_primary_raw(frame_view(rtg, 0), WIDTH, HEIGHT, tile, hits.data_ptr(), None, ctr.data_ptr())
+        torch.cuda.synchronize(dev)
+        c = ctr.view(n_rays, 2).to(torch.int64).sum(dim=0).cpu().numpy()
+        nodes_per_ray, tris_per_ray = c[0] / n_rays, c[1] / n_rays
+        bytes_per_ray = nodes_per_ray * 64.0 + tris_per_ray * 72.0 + 0.0 + 16.0
+        alg_bytes = bytes_per_ray * n_rays
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        mrays = args.steps * world * n_rays / elapsed / 1e6
+
+        cpu = None
+        if not args.no_cpu:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import orc
+            cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+            obvh = orc.OracleBvh(flat=bvh.view)
+            oscene = orc.OracleScene([orc.oracle_object(obj, obvh)])
+            t0 = time.perf_counter()
+            c_hits, _, _ = oscene.render_primary(frame_view(rtg, 0), WIDTH, HEIGHT, threads=cores)
+            cpu_s = time.perf_counter() - t0
+            scene.render_primary_raw(frame_view(rtg, 0), WIDTH, HEIGHT, tile, hits.data_ptr())
+            torch.cuda.synchronize(dev)
+            g = np.frombuffer(hits.cpu().numpy().tobytes(), dtype=rtg.HIT_DTYPE)
+            mism = int(((g["object"] != c_hits["object"]) | (g["leaf"] != c_hits["leaf"]) |
+                        (g["t"].view(np.uint64) != c_hits["t"].view(np.uint64))).sum())
+            cpu = {"value": round(n_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                   "sample": f"one full {WIDTH}x{HEIGHT} frame (frame 0), {n_rays} rays, {cpu_s:.2f} s",
+                   "hit_id_mismatches_vs_gpu": mism}
+
+        out = {
+            "metric": "Mrays/s, 1M-tri BVH scene", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"config 2: {2 * nx * ny}-triangle terrain BVH ({bvh.n_nodes} nodes, depth {bvh.depth}), "
+                                   f"{WIDTH}x{HEIGHT} primary rays per step per GPU, closest-hit ids",
+                       "traversal": "library default" if args.traversal < 0 else ("short-stack" if args.traversal == 0 else "threaded"),
+                       "parallelism": f"frames sharded over {world} GPU(s), BVH replicated" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "host_bvh_build_s": round(build_s, 2)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_render_primary",
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
+                         "nodes_per_ray": round(float(nodes_per_ray), 2), "tris_per_ray": round(float(tris_per_ray), 2)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

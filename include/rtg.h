@@ -1,0 +1,240 @@
+/*
+ * rtg.h -- C ABI of the MI355X (gfx950) ray-cast / BVH-traversal path.
+ *
+ * This is the drop-in boundary for the per-pixel ray-cast path of
+ * nathdobson/raytracer.  The reference has no FFI of its own; its seams are the
+ * Rust generics `Object::raycast` (src/render/object.rs:33-35), the frame API
+ * `Scene`/`Renderer` (src/render/renderer.rs:44-53,106,115,379) and the flat
+ * `Bvh` (src/tree/bvh.rs:14-24,80,107,134).  Every entry point below names the
+ * reference interface it replaces.  A Rust `extern "C"` block can bind this
+ * header 1:1: plain pointers, sizes and PODs only, no C++ or torch types.
+ *
+ * Conventions
+ *  - every function returns 0 (RTG_OK) or a negative RTG_E_* code; the message
+ *    is available from rtg_last_error().  The reference panics instead
+ *    (e.g. src/render/object.rs:45-46, src/tree/bvh.rs:109); panics must not
+ *    cross a C ABI, so they become error codes.
+ *  - "no hit" is not an error: object = leaf = RTG_NONE, t = +inf.
+ *  - all arithmetic is IEEE binary64 without contraction, in the reference's
+ *    operation order, so hit ids and hit times are bit-identical to the CPU
+ *    renderer's.
+ *  - input arrays are caller-owned host memory, copied at create time.  Output
+ *    pointers may be host pointers (the call synchronises and copies back) or
+ *    device pointers on the context's GPU (the call is asynchronous on the
+ *    context's stream).
+ *  - one rtg_ctx per GPU; calls on one ctx are serialised by the caller
+ *    (mirrors the single `&mut self` caller of Renderer::render); distinct
+ *    contexts may be driven from distinct host threads.
+ */
+#ifndef RTG_H
+#define RTG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTG_OK 0
+#define RTG_E_INVALID (-1)     /* bad argument / malformed tree           */
+#define RTG_E_HIP (-2)         /* a HIP runtime call failed               */
+#define RTG_E_NOMEM (-3)       /* host or device allocation failed        */
+#define RTG_E_NODEVICE (-4)    /* no usable gfx950 device                 */
+#define RTG_E_UNSUPPORTED (-5) /* valid request the build does not cover  */
+#define RTG_E_LIMIT (-6)       /* size beyond a documented maximum        */
+
+#define RTG_NONE 0xFFFFFFFFu
+
+typedef struct rtg_ctx rtg_ctx;
+typedef struct rtg_mesh rtg_mesh;
+typedef struct rtg_scene rtg_scene;
+
+/* ---- plain data ------------------------------------------------------- */
+
+/* One flattened BVH node: `BvhEntry` (src/tree/bvh.rs:14-18).  Children and
+ * leaves are index ranges [begin,end) into the node / leaf arrays. */
+typedef struct {
+    double lo[3];
+    double hi[3];
+    uint32_t child_begin, child_end;
+    uint32_t leaf_begin, leaf_end;
+} rtg_bvh_node;
+
+/* One leaf: the three vertex positions of a `TriVerts` / `Triangle`
+ * (src/geo/triangle.rs:7-9). */
+typedef struct {
+    double p[3][3];
+} rtg_tri;
+
+/* A host-flattened `Bvh` (src/tree/bvh.rs:20-24).  `vertex_normals` is either
+ * NULL or n_leaves x 3 x 3 doubles used for the interpolated normal. */
+typedef struct {
+    const rtg_bvh_node *nodes;
+    uint64_t n_nodes;
+    const rtg_tri *leaves;
+    uint64_t n_leaves;
+    const double *vertex_normals;
+    uint32_t root;
+} rtg_bvh;
+
+/* `Material` (src/render/material.rs:3-7). */
+typedef struct {
+    double diffuse[3];
+    double n1, n2;          /* dielectric indices, used when has_dielectric */
+    int32_t has_dielectric;
+    int32_t _pad;
+} rtg_material;
+
+/* `Transform` (src/geo/transform.rs:16-21), the three matrices the ray path
+ * reads; row-major. */
+typedef struct {
+    double forward[16];
+    double reverse[16];
+    double forward_norm[9];
+} rtg_transform;
+
+enum { RTG_SPHERE = 0, RTG_MESH = 1, RTG_PLANE = 2, RTG_PATCHES = 3 };
+
+/* One `TransformObject<AnyObject>` (src/render/transform_object.rs:6-9,
+ * src/render/any_object.rs:9-13). */
+typedef struct {
+    int32_t kind;
+    int32_t _pad;
+    rtg_transform transform;
+    rtg_material material;   /* sphere, mesh, patches; plane: material1 */
+    rtg_material material2;  /* plane only (src/render/plane_object.rs:8-14) */
+    double sphere_center[3]; /* `Sphere` (src/geo/sphere.rs:14-17) */
+    double sphere_radius;
+    double plane_position[3];
+    double plane_tan1[3];
+    double plane_tan2[3];
+    rtg_mesh *mesh;          /* kind MESH / PATCHES: a handle from rtg_mesh_create */
+} rtg_object;
+
+/* `SceneObject` (src/render/scene_object.rs:9-11): objects in vector order. */
+typedef struct {
+    const rtg_object *objects;
+    uint32_t n_objects;
+} rtg_scene_desc;
+
+/* `View` (src/geo/view.rs:6-9) with tan(fov/2) evaluated by the host libm. */
+typedef struct {
+    double orig[3];
+    double tan_half_fov[2];
+} rtg_view;
+
+/* `Light` (src/render/renderer.rs:38-42): sphere.orig and color; the light
+ * radius is stored by the reference but never read by shading. */
+typedef struct {
+    double position[3];
+    double color[3];
+} rtg_light;
+
+typedef struct {
+    uint32_t x0, y0, w, h;
+} rtg_rect;
+
+/* Compact hit id: `Manifold{array:[leaf, object]}` + `time`
+ * (src/render/object.rs:12-16,20). */
+typedef struct {
+    uint32_t object;
+    uint32_t leaf;
+    double t;
+} rtg_hit;
+
+/* Full `RaycastPoint` (src/render/object.rs:18-27).  manifold_len == 0 marks
+ * "no hit" (every scene-level hit has at least the object index pushed). */
+typedef struct {
+    double time;
+    double position[3];
+    double inter_normal[3];
+    double geo_normal[3];
+    double manifold_point[2];
+    uint32_t manifold[2];
+    uint32_t manifold_len;
+    uint32_t material_slot; /* object*2 + (1 if the plane's material2) */
+} rtg_point;
+
+/* Per-ray traversal work, for the algorithmic-bytes figure. */
+typedef struct {
+    uint32_t nodes_visited;
+    uint32_t tris_tested;
+} rtg_ray_counters;
+
+/* ---- context ---------------------------------------------------------- */
+
+/* No reference counterpart (the reference is CPU-only): binds a HIP device. */
+int rtg_ctx_create(int hip_device, rtg_ctx **out);
+void rtg_ctx_destroy(rtg_ctx *ctx);
+/* Message for the last failing call on this ctx (ctx == NULL: last failing
+ * create on this thread).  Replaces the reference's panic messages. */
+const char *rtg_last_error(rtg_ctx *ctx);
+/* Launch on a caller-owned hipStream_t (NULL restores the ctx's own stream). */
+int rtg_ctx_set_stream(rtg_ctx *ctx, void *hip_stream);
+void *rtg_ctx_get_stream(rtg_ctx *ctx);
+int rtg_ctx_synchronize(rtg_ctx *ctx);
+/* Options: "traversal" 0 = short-stack (VGPR window + LDS spill),
+ *                      1 = threaded pre-order (skip links). */
+int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value);
+
+/* Restates `Transform::from(Mat4)` (src/geo/transform.rs:51-58) with the
+ * inverse formulas of src/math/mat.rs:80-87,100-154 for callers that only hold
+ * the forward matrix. */
+int rtg_transform_from_forward(const double forward[16], rtg_transform *out);
+
+/* ---- geometry --------------------------------------------------------- */
+
+/* Uploads a flattened `Bvh`; replaces holding an `Arc<Bvh>`
+ * (src/render/mesh_object.rs:10-13).  The tree is validated (ranges in
+ * bounds, acyclic, every node reachable at most once). */
+int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out);
+void rtg_mesh_destroy(rtg_mesh *mesh);
+/* `Bvh::bounds` (src/tree/bvh.rs:134-136): lo[3], hi[3] of the root. */
+int rtg_mesh_bounds(const rtg_mesh *mesh, double out_lo_hi[6]);
+
+/* Replaces `SceneObject::new` (src/render/scene_object.rs:13-17). */
+int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out);
+void rtg_scene_destroy(rtg_scene *scene);
+
+/* ---- the hot path ----------------------------------------------------- */
+
+/* Primary rays of a pixel rectangle: replaces the pixel pass
+ * `pixels.into_par_iter().map(render_pixel)` (src/render/renderer.rs:141-160)
+ * down to `scene_object.raycast(ray, None)` (renderer.rs:316).  Outputs are
+ * row-major over the tile: index (y - y0) * w + (x - x0).  out_points and
+ * out_counters may be NULL. */
+int rtg_render_primary(rtg_scene *scene, const rtg_view *view, uint32_t width, uint32_t height,
+                       rtg_rect tile, rtg_hit *out_hits, rtg_point *out_points,
+                       rtg_ray_counters *out_counters);
+
+/* Batched `Object::raycast(ray, None)` (src/render/object.rs:33-35,
+ * src/render/scene_object.rs:19-36) for arbitrary rays: rays6 holds
+ * orig.xyz, dir.xyz per ray.  out_points / out_counters may be NULL. */
+int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *out_hits,
+              rtg_point *out_points, rtg_ray_counters *out_counters);
+
+/* `compute_direct_irrad` x `material.diffuse` (src/render/renderer.rs:184-205,
+ * 270-277) for n hit points (one shadow ray per light, closest-hit query).
+ * rgb_out: 3 doubles per point, rgba8_out (optional): PQ-encoded 8-bit
+ * (src/geo/color.rs:15-17 applied to c/80, src/render/image.rs:39). */
+int rtg_shade_direct(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights,
+                     const rtg_point *points, uint64_t n_points, double *rgb_out,
+                     uint8_t *rgba8_out);
+
+/* Fused frame: ray generation, closest hit, the specular path tree up to
+ * `max_depth` surface interactions (src/render/renderer.rs:284-378; depth 1 =
+ * primary hit only, the reference uses 4) and direct shading, i.e.
+ * `raytrace_pixel` (renderer.rs:266-283) with the photon term disabled.
+ * Any of out_rgb / out_rgba8 / out_hits may be NULL. */
+int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *lights,
+                     uint32_t n_lights, uint32_t width, uint32_t height, rtg_rect tile,
+                     uint32_t max_depth, double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits);
+
+/* Library build info: "rtg <version> gfx950". */
+const char *rtg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTG_H */

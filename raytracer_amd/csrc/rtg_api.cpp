@@ -1,0 +1,655 @@
+// rtg_api.cpp -- the C ABI of include/rtg.h over the gfx950 kernels.
+//
+// Host-side duties only: validate and re-lay-out the caller's flattened BVH for
+// the GPU, own device memory and the stream, route host/device pointers, and
+// turn every failure into an error code + message (nothing throws across the
+// ABI).  There is no CPU fallback: without a usable HIP device every entry
+// point that needs one fails with RTG_E_NODEVICE / RTG_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rtg_launch.hpp"
+
+using namespace rtg;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+} // namespace
+
+struct rtg_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int traversal = 0;
+    std::string err;
+    std::map<std::string, DeviceBuffer> scratch;
+};
+
+struct rtg_mesh {
+    rtg_ctx *ctx = nullptr;
+    DevMesh dev{};
+    void *d_nodes = nullptr, *d_tnodes = nullptr, *d_tris = nullptr, *d_normals = nullptr;
+    double bounds[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t n_leaves = 0;
+};
+
+struct rtg_scene {
+    rtg_ctx *ctx = nullptr;
+    DevScene dev{};
+    void *d_objects = nullptr;
+    uint32_t max_depth = 0;
+};
+
+namespace {
+
+int fail(rtg_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (void)hipGetLastError();                                                              \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RTG_E_NOMEM : RTG_E_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                                   \
+        }                                                                                         \
+    } while (0)
+
+int bind_device(rtg_ctx *ctx) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return RTG_OK;
+}
+
+// True when `p` can be dereferenced by a kernel on the ctx's device.
+bool is_device_pointer(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int scratch_get(rtg_ctx *ctx, const char *name, size_t bytes, void **out) {
+    DeviceBuffer &b = ctx->scratch[name];
+    if (b.bytes < bytes) {
+        if (b.ptr) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipFree(b.ptr));
+            b.ptr = nullptr;
+            b.bytes = 0;
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_TRY(ctx, hipMalloc(&b.ptr, want));
+        b.bytes = want;
+    }
+    *out = b.ptr;
+    return RTG_OK;
+}
+
+// An output the kernel writes: the caller's own device pointer, or a staging
+// buffer that is copied back to the caller's host memory after the launch.
+struct Out {
+    void *user = nullptr;
+    void *dev = nullptr;
+    size_t bytes = 0;
+    bool staged = false;
+};
+int out_prepare(rtg_ctx *ctx, const char *name, void *user, size_t bytes, Out &o) {
+    o.user = user;
+    o.bytes = bytes;
+    if (!user || bytes == 0) {
+        o.dev = nullptr;
+        return RTG_OK;
+    }
+    if (is_device_pointer(user)) {
+        o.dev = user;
+        return RTG_OK;
+    }
+    o.staged = true;
+    return scratch_get(ctx, name, bytes, &o.dev);
+}
+int out_finish(rtg_ctx *ctx, Out &o) {
+    if (o.staged && o.dev) HIP_TRY(ctx, hipMemcpyAsync(o.user, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return RTG_OK;
+}
+// An input the kernel reads: device pointer as is, host pointer uploaded.
+int in_prepare(rtg_ctx *ctx, const char *name, const void *user, size_t bytes, const void **dev) {
+    if (!user || bytes == 0) {
+        *dev = nullptr;
+        return RTG_OK;
+    }
+    if (is_device_pointer(user)) {
+        *dev = user;
+        return RTG_OK;
+    }
+    void *d = nullptr;
+    int rc = scratch_get(ctx, name, bytes, &d);
+    if (rc != RTG_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d, user, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev = d;
+    return RTG_OK;
+}
+
+int upload(rtg_ctx *ctx, const void *host, size_t bytes, void **dev) {
+    *dev = nullptr;
+    if (bytes == 0) return RTG_OK;
+    HIP_TRY(ctx, hipMalloc(dev, bytes));
+    hipError_t e = hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(*dev);
+        *dev = nullptr;
+        return fail(ctx, RTG_E_HIP, "hipMemcpy(H2D, %zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    return RTG_OK;
+}
+
+// Mat3::inverse / Mat4::inverse in the reference's operation order
+// (src/math/mat.rs:80-87,100-154); Transform::from (src/geo/transform.rs:51-58).
+void invert3(const double *x, double *r) {
+    const double a = x[0], b = x[1], c = x[2], d = x[3], e = x[4], f = x[5], g = x[6], h = x[7], i = x[8];
+    const double s = 1.0 / (a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g));
+    r[0] = (e * i - f * h) * s;
+    r[1] = (c * h - b * i) * s;
+    r[2] = (b * f - c * e) * s;
+    r[3] = (f * g - d * i) * s;
+    r[4] = (a * i - c * g) * s;
+    r[5] = (c * d - a * f) * s;
+    r[6] = (d * h - e * g) * s;
+    r[7] = (b * g - a * h) * s;
+    r[8] = (a * e - b * d) * s;
+}
+void invert4(const double *m, double *n) {
+    // 2x2 minors named by (rows)(columns), as the reference names them
+    const double m00 = m[0], m01 = m[1], m02 = m[2], m03 = m[3], m10 = m[4], m11 = m[5], m12 = m[6], m13 = m[7];
+    const double m20 = m[8], m21 = m[9], m22 = m[10], m23 = m[11], m30 = m[12], m31 = m[13], m32 = m[14], m33 = m[15];
+    const double a2323 = m22 * m33 - m23 * m32, a1323 = m21 * m33 - m23 * m31, a1223 = m21 * m32 - m22 * m31;
+    const double a0323 = m20 * m33 - m23 * m30, a0223 = m20 * m32 - m22 * m30, a0123 = m20 * m31 - m21 * m30;
+    const double a2313 = m12 * m33 - m13 * m32, a1313 = m11 * m33 - m13 * m31, a1213 = m11 * m32 - m12 * m31;
+    const double a2312 = m12 * m23 - m13 * m22, a1312 = m11 * m23 - m13 * m21, a1212 = m11 * m22 - m12 * m21;
+    const double a0313 = m10 * m33 - m13 * m30, a0213 = m10 * m32 - m12 * m30, a0312 = m10 * m23 - m13 * m20;
+    const double a0212 = m10 * m22 - m12 * m20, a0113 = m10 * m31 - m11 * m30, a0112 = m10 * m21 - m11 * m20;
+    const double det = 1.0 / (m00 * (m11 * a2323 - m12 * a1323 + m13 * a1223) -
+                              m01 * (m10 * a2323 - m12 * a0323 + m13 * a0223) +
+                              m02 * (m10 * a1323 - m11 * a0323 + m13 * a0123) -
+                              m03 * (m10 * a1223 - m11 * a0223 + m12 * a0123));
+    n[0] = det * (m11 * a2323 - m12 * a1323 + m13 * a1223);
+    n[1] = det * -(m01 * a2323 - m02 * a1323 + m03 * a1223);
+    n[2] = det * (m01 * a2313 - m02 * a1313 + m03 * a1213);
+    n[3] = det * -(m01 * a2312 - m02 * a1312 + m03 * a1212);
+    n[4] = det * -(m10 * a2323 - m12 * a0323 + m13 * a0223);
+    n[5] = det * (m00 * a2323 - m02 * a0323 + m03 * a0223);
+    n[6] = det * -(m00 * a2313 - m02 * a0313 + m03 * a0213);
+    n[7] = det * (m00 * a2312 - m02 * a0312 + m03 * a0212);
+    n[8] = det * (m10 * a1323 - m11 * a0323 + m13 * a0123);
+    n[9] = det * -(m00 * a1323 - m01 * a0323 + m03 * a0123);
+    n[10] = det * (m00 * a1313 - m01 * a0313 + m03 * a0113);
+    n[11] = det * -(m00 * a1312 - m01 * a0312 + m03 * a0112);
+    n[12] = det * -(m10 * a1223 - m11 * a0223 + m12 * a0123);
+    n[13] = det * (m00 * a1223 - m01 * a0223 + m02 * a0123);
+    n[14] = det * -(m00 * a1213 - m01 * a0213 + m02 * a0113);
+    n[15] = det * (m00 * a1212 - m01 * a0212 + m02 * a0112);
+}
+
+// Walks the caller's tree from the root: checks every range, rejects shared or
+// cyclic nodes, and emits (a) the reference-order node array with a
+// "last sibling" flag per node and (b) the pre-order threaded array with skip
+// links.  Iterative, so arbitrarily deep trees do not overflow the host stack.
+int layout_tree(rtg_ctx *ctx, const rtg_bvh *bvh, std::vector<DevNode> &ref_nodes, std::vector<DevNode> &thr_nodes,
+                uint32_t &depth_out) {
+    const uint64_t nn = bvh->n_nodes, nl = bvh->n_leaves;
+    ref_nodes.assign((size_t)nn, DevNode{});
+    thr_nodes.clear();
+    thr_nodes.reserve((size_t)nn);
+    depth_out = 0;
+    if (nn == 0) return RTG_OK;
+    if (bvh->root >= nn) return fail(ctx, RTG_E_INVALID, "bvh root %u out of range (%llu nodes)", bvh->root, (unsigned long long)nn);
+    for (uint64_t i = 0; i < nn; i++) {
+        const rtg_bvh_node &s = bvh->nodes[i];
+        if (s.child_begin > s.child_end || s.child_end > nn)
+            return fail(ctx, RTG_E_INVALID, "bvh node %llu: child range [%u,%u) invalid", (unsigned long long)i, s.child_begin, s.child_end);
+        if (s.leaf_begin > s.leaf_end || s.leaf_end > nl)
+            return fail(ctx, RTG_E_INVALID, "bvh node %llu: leaf range [%u,%u) invalid", (unsigned long long)i, s.leaf_begin, s.leaf_end);
+        DevNode &d = ref_nodes[(size_t)i];
+        for (int k = 0; k < 3; k++) {
+            d.lo[k] = s.lo[k];
+            d.hi[k] = s.hi[k];
+        }
+        d.link = s.child_begin;
+        d.nchild = s.child_end - s.child_begin;
+        d.leaf_begin = s.leaf_begin;
+        d.leaf_count = s.leaf_end - s.leaf_begin;
+    }
+    std::vector<uint8_t> seen((size_t)nn, 0);
+    struct Frame {
+        uint32_t node, next_child, thr_index;
+    };
+    std::vector<Frame> stack;
+    auto enter = [&](uint32_t node) -> bool {
+        if (seen[node]) return false;
+        seen[node] = 1;
+        DevNode t = ref_nodes[node];
+        t.link = 0;
+        t.nchild = 0;
+        stack.push_back(Frame{node, bvh->nodes[node].child_begin, (uint32_t)thr_nodes.size()});
+        thr_nodes.push_back(t);
+        return true;
+    };
+    ref_nodes[bvh->root].nchild |= 0x80000000u;
+    enter(bvh->root);
+    while (!stack.empty()) {
+        if (stack.size() > depth_out) depth_out = (uint32_t)stack.size();
+        Frame &f = stack.back();
+        const rtg_bvh_node &s = bvh->nodes[f.node];
+        if (f.next_child < s.child_end) {
+            uint32_t c = f.next_child++;
+            if (c + 1 == s.child_end) ref_nodes[c].nchild |= 0x80000000u;
+            if (!enter(c)) return fail(ctx, RTG_E_INVALID, "bvh node %u is reachable twice (shared child or cycle)", c);
+        } else {
+            thr_nodes[f.thr_index].link = (uint32_t)thr_nodes.size();
+            stack.pop_back();
+        }
+    }
+    return RTG_OK;
+}
+
+int check_scene_call(rtg_scene *scene) {
+    if (!scene || !scene->ctx) return fail(nullptr, RTG_E_INVALID, "null scene");
+    return bind_device(scene->ctx);
+}
+
+// Per-launch scene view: picks the traversal and sizes the global stack
+// overflow slab for `threads` lanes when the deepest tree needs one.
+int scene_for_launch(rtg_scene *scene, uint64_t threads, DevScene &out) {
+    rtg_ctx *ctx = scene->ctx;
+    out = scene->dev;
+    out.traversal = (uint32_t)ctx->traversal;
+    out.overflow = nullptr;
+    out.overflow_levels = 0;
+    out.overflow_stride = 1;
+    const uint32_t on_chip = kRegLevels + kLdsLevels;
+    if (out.traversal == 0 && scene->max_depth > on_chip) {
+        uint64_t levels = scene->max_depth - on_chip;
+        uint64_t bytes = levels * threads * sizeof(uint32_t);
+        if (bytes > (8ull << 30)) {
+            out.traversal = 1; // depth-independent
+        } else {
+            void *p = nullptr;
+            int rc = scratch_get(ctx, "stack_overflow", (size_t)bytes, &p);
+            if (rc != RTG_OK) return rc;
+            out.overflow = (uint32_t *)p;
+            out.overflow_levels = (uint32_t)levels;
+            out.overflow_stride = (uint32_t)threads;
+        }
+    }
+    return RTG_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rtg_version(void) { return "rtg 0.1 gfx950"; }
+
+int rtg_ctx_create(int hip_device, rtg_ctx **out) {
+    if (!out) return fail(nullptr, RTG_E_INVALID, "rtg_ctx_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, RTG_E_NODEVICE, "no HIP device (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    }
+    if (hip_device < 0 || hip_device >= count)
+        return fail(nullptr, RTG_E_INVALID, "device %d out of range (%d devices)", hip_device, count);
+    rtg_ctx *ctx = new (std::nothrow) rtg_ctx();
+    if (!ctx) return fail(nullptr, RTG_E_NOMEM, "out of host memory");
+    ctx->device = hip_device;
+    e = hipSetDevice(hip_device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        delete ctx;
+        return fail(nullptr, RTG_E_HIP, "stream create on device %d: %s", hip_device, hipGetErrorString(e));
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return RTG_OK;
+}
+
+void rtg_ctx_destroy(rtg_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->scratch)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *rtg_last_error(rtg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rtg_ctx_set_stream(rtg_ctx *ctx, void *hip_stream) {
+    if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RTG_OK;
+}
+void *rtg_ctx_get_stream(rtg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int rtg_ctx_synchronize(rtg_ctx *ctx) {
+    if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
+    int rc = bind_device(ctx);
+    if (rc != RTG_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTG_OK;
+}
+
+int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) {
+    if (!ctx || !key) return fail(ctx, RTG_E_INVALID, "null ctx or key");
+    if (std::strcmp(key, "traversal") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, RTG_E_INVALID, "traversal must be 0 (short stack) or 1 (threaded)");
+        ctx->traversal = (int)value;
+        return RTG_OK;
+    }
+    return fail(ctx, RTG_E_INVALID, "unknown option '%s'", key);
+}
+
+int rtg_transform_from_forward(const double forward[16], rtg_transform *out) {
+    if (!forward || !out) return fail(nullptr, RTG_E_INVALID, "null argument");
+    std::memcpy(out->forward, forward, sizeof(out->forward));
+    invert4(forward, out->reverse);
+    double reverse_norm[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) reverse_norm[i * 3 + j] = forward[j * 4 + i];
+    invert3(reverse_norm, out->forward_norm);
+    return RTG_OK;
+}
+
+int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) {
+    if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
+    if (!bvh || !out) return fail(ctx, RTG_E_INVALID, "rtg_mesh_create: null argument");
+    *out = nullptr;
+    if ((bvh->n_nodes && !bvh->nodes) || (bvh->n_leaves && !bvh->leaves))
+        return fail(ctx, RTG_E_INVALID, "rtg_mesh_create: null array with non-zero count");
+    if (bvh->n_nodes >= 0x7FFFFFFFull || bvh->n_leaves >= 0x7FFFFFFFull)
+        return fail(ctx, RTG_E_LIMIT, "rtg_mesh_create: more than 2^31-1 nodes or leaves");
+    int rc = bind_device(ctx);
+    if (rc != RTG_OK) return rc;
+
+    std::vector<DevNode> ref_nodes, thr_nodes;
+    uint32_t depth = 0;
+    rc = layout_tree(ctx, bvh, ref_nodes, thr_nodes, depth);
+    if (rc != RTG_OK) return rc;
+    std::vector<DevTri> tris((size_t)bvh->n_leaves);
+    for (uint64_t i = 0; i < bvh->n_leaves; i++) {
+        std::memcpy(tris[(size_t)i].p, bvh->leaves[i].p, sizeof(double) * 9);
+        tris[(size_t)i].source = (uint32_t)i;
+        tris[(size_t)i].pad = 0;
+    }
+
+    rtg_mesh *m = new (std::nothrow) rtg_mesh();
+    if (!m) return fail(ctx, RTG_E_NOMEM, "out of host memory");
+    m->ctx = ctx;
+    m->n_leaves = bvh->n_leaves;
+    if (bvh->n_nodes) {
+        const rtg_bvh_node &r = bvh->nodes[bvh->root];
+        for (int k = 0; k < 3; k++) {
+            m->bounds[k] = r.lo[k];
+            m->bounds[3 + k] = r.hi[k];
+        }
+    }
+    rc = upload(ctx, ref_nodes.data(), ref_nodes.size() * sizeof(DevNode), &m->d_nodes);
+    if (rc == RTG_OK) rc = upload(ctx, thr_nodes.data(), thr_nodes.size() * sizeof(DevNode), &m->d_tnodes);
+    if (rc == RTG_OK) rc = upload(ctx, tris.data(), tris.size() * sizeof(DevTri), &m->d_tris);
+    if (rc == RTG_OK && bvh->vertex_normals)
+        rc = upload(ctx, bvh->vertex_normals, (size_t)bvh->n_leaves * 9 * sizeof(double), &m->d_normals);
+    if (rc != RTG_OK) {
+        rtg_mesh_destroy(m);
+        return rc;
+    }
+    m->dev.nodes = (const DevNode *)m->d_nodes;
+    m->dev.tnodes = (const DevNode *)m->d_tnodes;
+    m->dev.tris = (const DevTri *)m->d_tris;
+    m->dev.normals = (const double *)m->d_normals;
+    m->dev.n_nodes = (uint32_t)thr_nodes.size();
+    m->dev.root = bvh->root;
+    m->dev.depth = depth;
+    *out = m;
+    return RTG_OK;
+}
+
+void rtg_mesh_destroy(rtg_mesh *m) {
+    if (!m) return;
+    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    if (m->d_nodes) (void)hipFree(m->d_nodes);
+    if (m->d_tnodes) (void)hipFree(m->d_tnodes);
+    if (m->d_tris) (void)hipFree(m->d_tris);
+    if (m->d_normals) (void)hipFree(m->d_normals);
+    delete m;
+}
+
+int rtg_mesh_bounds(const rtg_mesh *mesh, double out[6]) {
+    if (!mesh || !out) return fail(nullptr, RTG_E_INVALID, "null argument");
+    std::memcpy(out, mesh->bounds, sizeof(mesh->bounds));
+    return RTG_OK;
+}
+
+int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) {
+    if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
+    if (!desc || !out) return fail(ctx, RTG_E_INVALID, "rtg_scene_create: null argument");
+    *out = nullptr;
+    if (desc->n_objects && !desc->objects) return fail(ctx, RTG_E_INVALID, "rtg_scene_create: null objects");
+    if (desc->n_objects >= 0x7FFFFFFFu) return fail(ctx, RTG_E_LIMIT, "too many objects");
+    int rc = bind_device(ctx);
+    if (rc != RTG_OK) return rc;
+    std::vector<DevObject> objs(desc->n_objects);
+    uint32_t max_depth = 0;
+    for (uint32_t i = 0; i < desc->n_objects; i++) {
+        const rtg_object &o = desc->objects[i];
+        DevObject &d = objs[i];
+        std::memset(&d, 0, sizeof(d));
+        d.kind = o.kind;
+        std::memcpy(d.reverse, o.transform.reverse, sizeof(d.reverse));
+        std::memcpy(d.forward_norm, o.transform.forward_norm, sizeof(d.forward_norm));
+        auto mat = [](const rtg_material &m) {
+            DevMaterial x;
+            std::memcpy(x.diffuse, m.diffuse, sizeof(x.diffuse));
+            x.n1 = m.n1;
+            x.n2 = m.n2;
+            x.has_dielectric = m.has_dielectric;
+            x.pad = 0;
+            return x;
+        };
+        d.material = mat(o.material);
+        d.material2 = mat(o.material2);
+        std::memcpy(d.sphere_center, o.sphere_center, sizeof(d.sphere_center));
+        d.sphere_radius = o.sphere_radius;
+        std::memcpy(d.plane_position, o.plane_position, sizeof(d.plane_position));
+        std::memcpy(d.plane_tan1, o.plane_tan1, sizeof(d.plane_tan1));
+        std::memcpy(d.plane_tan2, o.plane_tan2, sizeof(d.plane_tan2));
+        switch (o.kind) {
+        case RTG_SPHERE:
+        case RTG_PLANE:
+            break;
+        case RTG_MESH:
+            if (!o.mesh) return fail(ctx, RTG_E_INVALID, "object %u: mesh handle is null", i);
+            if (o.mesh->ctx != ctx) return fail(ctx, RTG_E_INVALID, "object %u: mesh belongs to another context", i);
+            d.mesh = o.mesh->dev;
+            if (o.mesh->dev.depth > max_depth) max_depth = o.mesh->dev.depth;
+            break;
+        case RTG_PATCHES:
+            return fail(ctx, RTG_E_UNSUPPORTED, "object %u: trispline patch objects are not built yet", i);
+        default:
+            return fail(ctx, RTG_E_INVALID, "object %u: unknown kind %d", i, o.kind);
+        }
+    }
+    rtg_scene *s = new (std::nothrow) rtg_scene();
+    if (!s) return fail(ctx, RTG_E_NOMEM, "out of host memory");
+    s->ctx = ctx;
+    s->max_depth = max_depth;
+    rc = upload(ctx, objs.data(), objs.size() * sizeof(DevObject), &s->d_objects);
+    if (rc != RTG_OK) {
+        delete s;
+        return rc;
+    }
+    s->dev.objects = (const DevObject *)s->d_objects;
+    s->dev.n_objects = desc->n_objects;
+    s->dev.traversal = 0;
+    s->dev.overflow = nullptr;
+    s->dev.overflow_levels = 0;
+    s->dev.overflow_stride = 1;
+    *out = s;
+    return RTG_OK;
+}
+
+void rtg_scene_destroy(rtg_scene *s) {
+    if (!s) return;
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    if (s->d_objects) (void)hipFree(s->d_objects);
+    delete s;
+}
+
+int rtg_render_primary(rtg_scene *scene, const rtg_view *view, uint32_t width, uint32_t height, rtg_rect tile,
+                       rtg_hit *out_hits, rtg_point *out_points, rtg_ray_counters *out_counters) {
+    int rc = check_scene_call(scene);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = scene->ctx;
+    if (!view) return fail(ctx, RTG_E_INVALID, "rtg_render_primary: view is null");
+    if (width == 0 || height == 0) return fail(ctx, RTG_E_INVALID, "rtg_render_primary: empty image");
+    if ((uint64_t)tile.x0 + tile.w > width || (uint64_t)tile.y0 + tile.h > height)
+        return fail(ctx, RTG_E_INVALID, "rtg_render_primary: tile [%u+%u, %u+%u] outside %ux%u", tile.x0, tile.w, tile.y0, tile.h, width, height);
+    uint64_t n = (uint64_t)tile.w * tile.h;
+    if (n == 0) return RTG_OK;
+    if (!out_hits && !out_points && !out_counters) return fail(ctx, RTG_E_INVALID, "rtg_render_primary: no output requested");
+    uint64_t tiles = (uint64_t)((tile.w + 15) / 16) * ((tile.h + 15) / 16);
+    if (tiles > 0x7FFFFFFFull) return fail(ctx, RTG_E_LIMIT, "rtg_render_primary: tile too large");
+    Out oh, op, oc;
+    if ((rc = out_prepare(ctx, "out_hits", out_hits, n * sizeof(rtg_hit), oh)) != RTG_OK) return rc;
+    if ((rc = out_prepare(ctx, "out_points", out_points, n * sizeof(rtg_point), op)) != RTG_OK) return rc;
+    if ((rc = out_prepare(ctx, "out_counters", out_counters, n * sizeof(rtg_ray_counters), oc)) != RTG_OK) return rc;
+    DevScene ds;
+    if ((rc = scene_for_launch(scene, tiles * kBlock, ds)) != RTG_OK) return rc;
+    HIP_TRY(ctx, launch_render_primary(ctx->stream, ds, *view, width, height, tile, (rtg_hit *)oh.dev,
+                                       (rtg_point *)op.dev, (rtg_ray_counters *)oc.dev));
+    if ((rc = out_finish(ctx, oh)) != RTG_OK) return rc;
+    if ((rc = out_finish(ctx, op)) != RTG_OK) return rc;
+    if ((rc = out_finish(ctx, oc)) != RTG_OK) return rc;
+    if (oh.staged || op.staged || oc.staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTG_OK;
+}
+
+int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *out_hits, rtg_point *out_points,
+              rtg_ray_counters *out_counters) {
+    int rc = check_scene_call(scene);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = scene->ctx;
+    if (n_rays == 0) return RTG_OK;
+    if (!rays6) return fail(ctx, RTG_E_INVALID, "rtg_trace: rays6 is null");
+    if (!out_hits && !out_points && !out_counters) return fail(ctx, RTG_E_INVALID, "rtg_trace: no output requested");
+    if (n_rays > (0x7FFFFFFFull * kBlock)) return fail(ctx, RTG_E_LIMIT, "rtg_trace: too many rays for one launch");
+    if ((uintptr_t)rays6 % 16 != 0 && is_device_pointer(rays6))
+        return fail(ctx, RTG_E_INVALID, "rtg_trace: device ray buffer must be 16-byte aligned");
+    const void *d_rays = nullptr;
+    if ((rc = in_prepare(ctx, "in_rays", rays6, n_rays * 6 * sizeof(double), &d_rays)) != RTG_OK) return rc;
+    Out oh, op, oc;
+    if ((rc = out_prepare(ctx, "out_hits", out_hits, n_rays * sizeof(rtg_hit), oh)) != RTG_OK) return rc;
+    if ((rc = out_prepare(ctx, "out_points", out_points, n_rays * sizeof(rtg_point), op)) != RTG_OK) return rc;
+    if ((rc = out_prepare(ctx, "out_counters", out_counters, n_rays * sizeof(rtg_ray_counters), oc)) != RTG_OK) return rc;
+    DevScene ds;
+    uint64_t threads = (n_rays + kBlock - 1) / kBlock * kBlock;
+    if ((rc = scene_for_launch(scene, threads, ds)) != RTG_OK) return rc;
+    HIP_TRY(ctx, launch_trace(ctx->stream, ds, (const double *)d_rays, n_rays, (rtg_hit *)oh.dev, (rtg_point *)op.dev,
+                              (rtg_ray_counters *)oc.dev));
+    if ((rc = out_finish(ctx, oh)) != RTG_OK) return rc;
+    if ((rc = out_finish(ctx, op)) != RTG_OK) return rc;
+    if ((rc = out_finish(ctx, oc)) != RTG_OK) return rc;
+    if (oh.staged || op.staged || oc.staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTG_OK;
+}
+
+int rtg_shade_direct(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const rtg_point *points,
+                     uint64_t n_points, double *rgb_out, uint8_t *rgba8_out) {
+    int rc = check_scene_call(scene);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = scene->ctx;
+    if (n_points == 0) return RTG_OK;
+    if (!points) return fail(ctx, RTG_E_INVALID, "rtg_shade_direct: points is null");
+    if (n_lights && !lights) return fail(ctx, RTG_E_INVALID, "rtg_shade_direct: lights is null");
+    if (!rgb_out && !rgba8_out) return fail(ctx, RTG_E_INVALID, "rtg_shade_direct: no output requested");
+    if (n_points > (0x7FFFFFFFull * kBlock)) return fail(ctx, RTG_E_LIMIT, "rtg_shade_direct: too many points for one launch");
+    const void *d_lights = nullptr, *d_points = nullptr;
+    if ((rc = in_prepare(ctx, "in_lights", lights, (size_t)n_lights * sizeof(rtg_light), &d_lights)) != RTG_OK) return rc;
+    if ((rc = in_prepare(ctx, "in_points", points, n_points * sizeof(rtg_point), &d_points)) != RTG_OK) return rc;
+    Out orgb, o8;
+    if ((rc = out_prepare(ctx, "out_rgb", rgb_out, n_points * 3 * sizeof(double), orgb)) != RTG_OK) return rc;
+    if ((rc = out_prepare(ctx, "out_rgba8", rgba8_out, n_points * 4, o8)) != RTG_OK) return rc;
+    DevScene ds;
+    uint64_t threads = (n_points + kBlock - 1) / kBlock * kBlock;
+    if ((rc = scene_for_launch(scene, threads, ds)) != RTG_OK) return rc;
+    HIP_TRY(ctx, launch_shade_direct(ctx->stream, ds, (const rtg_light *)d_lights, n_lights, (const rtg_point *)d_points,
+                                     n_points, (double *)orgb.dev, (uint8_t *)o8.dev));
+    if ((rc = out_finish(ctx, orgb)) != RTG_OK) return rc;
+    if ((rc = out_finish(ctx, o8)) != RTG_OK) return rc;
+    if (orgb.staged || o8.staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTG_OK;
+}
+
+int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *lights, uint32_t n_lights,
+                     uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth, double *out_rgb,
+                     uint8_t *out_rgba8, rtg_hit *out_hits) {
+    int rc = check_scene_call(scene);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = scene->ctx;
+    if (!view) return fail(ctx, RTG_E_INVALID, "rtg_render_frame: view is null");
+    if (n_lights && !lights) return fail(ctx, RTG_E_INVALID, "rtg_render_frame: lights is null");
+    if (width == 0 || height == 0) return fail(ctx, RTG_E_INVALID, "rtg_render_frame: empty image");
+    if ((uint64_t)tile.x0 + tile.w > width || (uint64_t)tile.y0 + tile.h > height)
+        return fail(ctx, RTG_E_INVALID, "rtg_render_frame: tile outside the image");
+    if (max_depth > (uint32_t)8) return fail(ctx, RTG_E_LIMIT, "rtg_render_frame: max_depth %u exceeds 8", max_depth);
+    uint64_t n = (uint64_t)tile.w * tile.h;
+    if (n == 0) return RTG_OK;
+    if (!out_rgb && !out_rgba8 && !out_hits) return fail(ctx, RTG_E_INVALID, "rtg_render_frame: no output requested");
+    uint64_t tiles = (uint64_t)((tile.w + 15) / 16) * ((tile.h + 15) / 16);
+    if (tiles > 0x7FFFFFFFull) return fail(ctx, RTG_E_LIMIT, "rtg_render_frame: tile too large");
+    const void *d_lights = nullptr;
+    if ((rc = in_prepare(ctx, "in_lights", lights, (size_t)n_lights * sizeof(rtg_light), &d_lights)) != RTG_OK) return rc;
+    Out orgb, o8, oh;
+    if ((rc = out_prepare(ctx, "out_rgb", out_rgb, n * 3 * sizeof(double), orgb)) != RTG_OK) return rc;
+    if ((rc = out_prepare(ctx, "out_rgba8", out_rgba8, n * 4, o8)) != RTG_OK) return rc;
+    if ((rc = out_prepare(ctx, "out_hits", out_hits, n * sizeof(rtg_hit), oh)) != RTG_OK) return rc;
+    DevScene ds;
+    if ((rc = scene_for_launch(scene, tiles * kBlock, ds)) != RTG_OK) return rc;
+    HIP_TRY(ctx, launch_render_frame(ctx->stream, ds, *view, (const rtg_light *)d_lights, n_lights, width, height, tile,
+                                     max_depth, (double *)orgb.dev, (uint8_t *)o8.dev, (rtg_hit *)oh.dev));
+    if ((rc = out_finish(ctx, orgb)) != RTG_OK) return rc;
+    if ((rc = out_finish(ctx, o8)) != RTG_OK) return rc;
+    if ((rc = out_finish(ctx, oh)) != RTG_OK) return rc;
+    if (orgb.staged || o8.staged || oh.staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTG_OK;
+}
+
+} // extern "C"

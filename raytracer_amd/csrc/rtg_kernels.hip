@@ -1,0 +1,337 @@
+// rtg_kernels.hip -- gfx950 kernels of the ray-cast path and their launchers.
+//
+// One lane = one ray.  A wave64 covers an 8x8 pixel tile, a 256-thread block a
+// 16x16 tile, so the lanes of a wave walk neighbouring parts of the BVH.  Blocks
+// are dealt round-robin over the 8 XCDs, so block b is mapped to tile
+// chunk(b % 8) + b / 8: each XCD (and its private L2) renders one contiguous run
+// of tiles.
+#include "rtg_device.hpp"
+#include "rtg_launch.hpp"
+
+namespace rtg {
+
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nwg) {
+    // bijective for every nwg: XCD k owns q (+1 for the first r XCDs) consecutive tiles
+    uint32_t xcd = b & 7u, idx = b >> 3;
+    uint32_t q = nwg >> 3, r = nwg & 7u;
+    uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ TraceCtx make_trace_ctx(const DevScene &s, uint32_t *lds, uint64_t global_thread) {
+    TraceCtx tc;
+    tc.lds_col = lds + threadIdx.x;
+    tc.gstride = s.overflow_stride;
+    tc.glob_col = s.overflow ? s.overflow + (global_thread % s.overflow_stride) : nullptr;
+    return tc;
+}
+
+__device__ __forceinline__ void store_hit(rtg_hit *out, const SceneHit &h) {
+    // one 16-byte store per lane
+    uint64_t tb = __double_as_longlong(h.have ? h.t : kInf);
+    uint4 v;
+    v.x = h.have ? h.object : RTG_NONE;
+    v.y = h.have ? h.leaf : RTG_NONE;
+    v.z = (uint32_t)tb;
+    v.w = (uint32_t)(tb >> 32);
+    *reinterpret_cast<uint4 *>(out) = v;
+}
+
+template <bool COUNT, bool POINTS>
+__global__ __launch_bounds__(kBlock) void k_render_primary(DevScene s, rtg_view view, uint32_t width,
+                                                            uint32_t height, rtg_rect tile, uint32_t tiles_x,
+                                                            uint32_t n_tiles, rtg_hit *out_hits,
+                                                            rtg_point *out_points, rtg_ray_counters *out_counters) {
+    __shared__ uint32_t lds[kLdsLevels * kBlock];
+    uint32_t t = xcd_remap(blockIdx.x, n_tiles);
+    uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t px = tx * 16 + (wave & 1u) * 8 + (lane & 7u);
+    uint32_t py = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (px >= tile.w || py >= tile.h) return;
+    uint64_t idx = (uint64_t)py * tile.w + px;
+    TraceCtx tc = make_trace_ctx(s, lds, (uint64_t)blockIdx.x * kBlock + threadIdx.x);
+    Ray ray = primary_ray(view, tile.x0 + px, tile.y0 + py, width, height);
+    Counter ctr;
+    ctr.nodes = 0;
+    ctr.tris = 0;
+    SceneHit h = scene_closest<COUNT>(s, ray, tc, ctr);
+    if (out_hits) store_hit(out_hits + idx, h);
+    if (POINTS) scene_point(s, ray, h, out_points[idx]);
+    if (COUNT) {
+        out_counters[idx].nodes_visited = ctr.nodes;
+        out_counters[idx].tris_tested = ctr.tris;
+    }
+}
+
+template <bool COUNT, bool POINTS>
+__global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const double *__restrict__ rays6, uint64_t n,
+                                                   rtg_hit *out_hits, rtg_point *out_points,
+                                                   rtg_ray_counters *out_counters) {
+    __shared__ uint32_t lds[kLdsLevels * kBlock];
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= n) return;
+    TraceCtx tc = make_trace_ctx(s, lds, gid);
+    // 48 B per ray, 16-B aligned: three 128-bit loads
+    const double2 *q = reinterpret_cast<const double2 *>(rays6 + gid * 6);
+    double2 a = q[0], b = q[1], c = q[2];
+    Ray ray{mk(a.x, a.y, b.x), mk(b.y, c.x, c.y)};
+    Counter ctr;
+    ctr.nodes = 0;
+    ctr.tris = 0;
+    SceneHit h = scene_closest<COUNT>(s, ray, tc, ctr);
+    if (out_hits) store_hit(out_hits + gid, h);
+    if (POINTS) scene_point(s, ray, h, out_points[gid]);
+    if (COUNT) {
+        out_counters[gid].nodes_visited = ctr.nodes;
+        out_counters[gid].tris_tested = ctr.tris;
+    }
+}
+
+// compute_direct_irrad x diffuse for already-built points (renderer.rs:184-205,270-277).
+__global__ __launch_bounds__(kBlock) void k_shade_direct(DevScene s, const rtg_light *__restrict__ lights,
+                                                          uint32_t n_lights, const rtg_point *__restrict__ points,
+                                                          uint64_t n, double *rgb_out, uint8_t *rgba8_out) {
+    __shared__ uint32_t lds[kLdsLevels * kBlock];
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= n) return;
+    TraceCtx tc = make_trace_ctx(s, lds, gid);
+    const rtg_point &pt = points[gid];
+    V3 total = mk(0.0, 0.0, 0.0);
+    if (pt.manifold_len != 0) {
+        Counter ctr;
+        V3 irrad = (mk(0.0, 0.0, 0.0) + direct_irrad<false>(s, lights, n_lights, ld3(pt.position),
+                                                             ld3(pt.inter_normal), tc, ctr)) +
+                   mk(0.0, 0.0, 0.0);
+        const DevMaterial &m = material_of_slot(s, pt.material_slot);
+        V3 dm = mk(irrad.x * m.diffuse[0], irrad.y * m.diffuse[1], irrad.z * m.diffuse[2]);
+        total = total + dm * 1.0;
+    }
+    if (rgb_out) {
+        rgb_out[gid * 3 + 0] = total.x;
+        rgb_out[gid * 3 + 1] = total.y;
+        rgb_out[gid * 3 + 2] = total.z;
+    }
+    if (rgba8_out) {
+        uchar4 c;
+        c.x = pq8(total.x);
+        c.y = pq8(total.y);
+        c.z = pq8(total.z);
+        c.w = 255;
+        reinterpret_cast<uchar4 *>(rgba8_out)[gid] = c;
+    }
+}
+
+// Dielectric::new (render/dielectric.rs:13-52).
+struct Dielectric {
+    double reflectance;
+    V3 reflect, refract;
+    bool has_refract;
+};
+__device__ __forceinline__ Dielectric dielectric_new(V3 inc, V3 signed_norm, double n1, double n2) {
+    inc = normalize(inc);
+    double d = dot(inc, signed_norm);
+    V3 norm;
+    double cos_i, n_i, n_t;
+    if (d < 0.0) {
+        norm = signed_norm;
+        cos_i = -d;
+        n_i = n1;
+        n_t = n2;
+    } else {
+        norm = neg(signed_norm);
+        cos_i = d;
+        n_i = n2;
+        n_t = n1;
+    }
+    double eta = n_i / n_t;
+    double s2i = 1.0 - cos_i * cos_i;
+    // f64::maximum(x, 0.0): NaN propagates
+    s2i = is_nan(s2i) ? s2i : (s2i > 0.0 ? s2i : 0.0);
+    double s2t = eta * eta * s2i;
+    Dielectric r;
+    r.refract = mk(0.0, 0.0, 0.0);
+    if (s2t >= 1.0) {
+        r.has_refract = false;
+        r.reflectance = 1.0;
+    } else {
+        double cos_t = __builtin_sqrt(1.0 - s2t);
+        r.has_refract = true;
+        r.refract = inc * eta + norm * (eta * cos_i - cos_t);
+        double r_par = ((n_t * cos_i) - (n_i * cos_t)) / ((n_t * cos_i) + (n_i * cos_t));
+        double r_perp = ((n_i * cos_i) - (n_t * cos_t)) / ((n_i * cos_i) + (n_t * cos_t));
+        r.reflectance = (r_par * r_par + r_perp * r_perp) / 2.0;
+    }
+    r.reflect = inc - (norm * 2.0) * dot(inc, norm);
+    return r;
+}
+
+// Fused frame: raytrace_pixel (render/renderer.rs:266-283) with the photon term
+// empty.  The specular recursion (renderer.rs:296-378, depth cap at :312) is
+// unrolled into an explicit stack of pending rays: a dielectric hit schedules
+// its refracted ray and continues with the reflected one, which reproduces the
+// reference's depth-first output order, so the radiance sum has the same
+// operation order.
+constexpr int kMaxSpecDepth = 8;
+struct Pending {
+    Ray ray;
+    double attenuation;
+    uint32_t depth;
+};
+
+__global__ __launch_bounds__(kBlock) void k_render_frame(DevScene s, rtg_view view,
+                                                          const rtg_light *__restrict__ lights, uint32_t n_lights,
+                                                          uint32_t width, uint32_t height, rtg_rect tile,
+                                                          uint32_t tiles_x, uint32_t n_tiles, uint32_t max_depth,
+                                                          double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits) {
+    __shared__ uint32_t lds[kLdsLevels * kBlock];
+    uint32_t t = xcd_remap(blockIdx.x, n_tiles);
+    uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t px = tx * 16 + (wave & 1u) * 8 + (lane & 7u);
+    uint32_t py = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (px >= tile.w || py >= tile.h) return;
+    uint64_t idx = (uint64_t)py * tile.w + px;
+    TraceCtx tc = make_trace_ctx(s, lds, (uint64_t)blockIdx.x * kBlock + threadIdx.x);
+    Counter ctr;
+
+    Pending stack[kMaxSpecDepth];
+    int sp = 0;
+    Ray ray = primary_ray(view, tile.x0 + px, tile.y0 + py, width, height);
+    double attenuation = 1.0;
+    uint32_t depth = 0;
+    bool live = max_depth > 0;
+    bool first = true;
+    V3 total = mk(0.0, 0.0, 0.0);
+    while (live) {
+        SceneHit h = scene_closest<false>(s, ray, tc, ctr);
+        if (first) {
+            if (out_hits) store_hit(out_hits + idx, h);
+            first = false;
+        }
+        bool cont = false;
+        if (h.have) {
+            rtg_point pt;
+            scene_point(s, ray, h, pt);
+            const DevMaterial &m = material_of_slot(s, pt.material_slot);
+            V3 irrad = (mk(0.0, 0.0, 0.0) + direct_irrad<false>(s, lights, n_lights, ld3(pt.position),
+                                                                 ld3(pt.inter_normal), tc, ctr)) +
+                       mk(0.0, 0.0, 0.0);
+            V3 dm = mk(irrad.x * m.diffuse[0], irrad.y * m.diffuse[1], irrad.z * m.diffuse[2]);
+            total = total + dm * attenuation;
+            if (m.has_dielectric && depth + 1 < max_depth) {
+                Dielectric di = dielectric_new(ray.d, ld3(pt.geo_normal), m.n1, m.n2);
+                V3 pos = ld3(pt.position);
+                if (di.has_refract && sp < kMaxSpecDepth) {
+                    stack[sp].ray = new_bounce(pos, di.refract);
+                    stack[sp].attenuation = attenuation * (1.0 - di.reflectance);
+                    stack[sp].depth = depth + 1;
+                    sp++;
+                }
+                ray = new_bounce(pos, di.reflect);
+                attenuation = attenuation * di.reflectance;
+                depth = depth + 1;
+                cont = true;
+            }
+        }
+        if (!cont) {
+            if (sp > 0) {
+                sp--;
+                ray = stack[sp].ray;
+                attenuation = stack[sp].attenuation;
+                depth = stack[sp].depth;
+            } else {
+                live = false;
+            }
+        }
+    }
+    if (first && out_hits) {
+        SceneHit none;
+        none.have = false;
+        none.t = kInf;
+        none.object = RTG_NONE;
+        none.leaf = RTG_NONE;
+        store_hit(out_hits + idx, none);
+    }
+    if (out_rgb) {
+        out_rgb[idx * 3 + 0] = total.x;
+        out_rgb[idx * 3 + 1] = total.y;
+        out_rgb[idx * 3 + 2] = total.z;
+    }
+    if (out_rgba8) {
+        uchar4 c;
+        c.x = pq8(total.x);
+        c.y = pq8(total.y);
+        c.z = pq8(total.z);
+        c.w = 255;
+        reinterpret_cast<uchar4 *>(out_rgba8)[idx] = c;
+    }
+}
+
+// ------------------------------------------------------------- launchers --
+static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+hipError_t launch_render_primary(hipStream_t stream, const DevScene &s, const rtg_view &view, uint32_t width,
+                                 uint32_t height, rtg_rect tile, rtg_hit *out_hits, rtg_point *out_points,
+                                 rtg_ray_counters *out_counters) {
+    uint32_t tiles_x = div_up(tile.w, 16), tiles_y = div_up(tile.h, 16);
+    uint32_t n_tiles = tiles_x * tiles_y;
+    if (n_tiles == 0) return hipSuccess;
+    dim3 grid(n_tiles), block(kBlock);
+    bool count = out_counters != nullptr, points = out_points != nullptr;
+    if (count && points)
+        hipLaunchKernelGGL((k_render_primary<true, true>), grid, block, 0, stream, s, view, width, height, tile,
+                           tiles_x, n_tiles, out_hits, out_points, out_counters);
+    else if (count)
+        hipLaunchKernelGGL((k_render_primary<true, false>), grid, block, 0, stream, s, view, width, height, tile,
+                           tiles_x, n_tiles, out_hits, out_points, out_counters);
+    else if (points)
+        hipLaunchKernelGGL((k_render_primary<false, true>), grid, block, 0, stream, s, view, width, height, tile,
+                           tiles_x, n_tiles, out_hits, out_points, out_counters);
+    else
+        hipLaunchKernelGGL((k_render_primary<false, false>), grid, block, 0, stream, s, view, width, height, tile,
+                           tiles_x, n_tiles, out_hits, out_points, out_counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(hipStream_t stream, const DevScene &s, const double *rays6, uint64_t n, rtg_hit *out_hits,
+                        rtg_point *out_points, rtg_ray_counters *out_counters) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((uint32_t)((n + kBlock - 1) / kBlock)), block(kBlock);
+    bool count = out_counters != nullptr, points = out_points != nullptr;
+    if (count && points)
+        hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, stream, s, rays6, n, out_hits, out_points,
+                           out_counters);
+    else if (count)
+        hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, stream, s, rays6, n, out_hits, out_points,
+                           out_counters);
+    else if (points)
+        hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, stream, s, rays6, n, out_hits, out_points,
+                           out_counters);
+    else
+        hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, stream, s, rays6, n, out_hits, out_points,
+                           out_counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_shade_direct(hipStream_t stream, const DevScene &s, const rtg_light *lights, uint32_t n_lights,
+                               const rtg_point *points, uint64_t n, double *rgb_out, uint8_t *rgba8_out) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((uint32_t)((n + kBlock - 1) / kBlock)), block(kBlock);
+    hipLaunchKernelGGL(k_shade_direct, grid, block, 0, stream, s, lights, n_lights, points, n, rgb_out, rgba8_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_frame(hipStream_t stream, const DevScene &s, const rtg_view &view, const rtg_light *lights,
+                               uint32_t n_lights, uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth,
+                               double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits) {
+    uint32_t tiles_x = div_up(tile.w, 16), tiles_y = div_up(tile.h, 16);
+    uint32_t n_tiles = tiles_x * tiles_y;
+    if (n_tiles == 0) return hipSuccess;
+    dim3 grid(n_tiles), block(kBlock);
+    hipLaunchKernelGGL(k_render_frame, grid, block, 0, stream, s, view, lights, n_lights, width, height, tile,
+                       tiles_x, n_tiles, max_depth, out_rgb, out_rgba8, out_hits);
+    return hipGetLastError();
+}
+
+} // namespace rtg

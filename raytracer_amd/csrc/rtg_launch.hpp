@@ -1,0 +1,20 @@
+// rtg_launch.hpp -- host-callable launchers of the kernels in rtg_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rtg_device.hpp"
+
+namespace rtg {
+
+hipError_t launch_render_primary(hipStream_t stream, const DevScene &s, const rtg_view &view, uint32_t width,
+                                 uint32_t height, rtg_rect tile, rtg_hit *out_hits, rtg_point *out_points,
+                                 rtg_ray_counters *out_counters);
+hipError_t launch_trace(hipStream_t stream, const DevScene &s, const double *rays6, uint64_t n, rtg_hit *out_hits,
+                        rtg_point *out_points, rtg_ray_counters *out_counters);
+hipError_t launch_shade_direct(hipStream_t stream, const DevScene &s, const rtg_light *lights, uint32_t n_lights,
+                               const rtg_point *points, uint64_t n, double *rgb_out, uint8_t *rgba8_out);
+hipError_t launch_render_frame(hipStream_t stream, const DevScene &s, const rtg_view &view, const rtg_light *lights,
+                               uint32_t n_lights, uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth,
+                               double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits);
+
+} // namespace rtg

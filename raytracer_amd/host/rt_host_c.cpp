@@ -1,0 +1,86 @@
+// rt_host_c.cpp -- C wrappers of the host library (see rt_host_c.h).
+#include "rt_host_c.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "rt_bvh.hpp"
+#include "rt_mesh.hpp"
+#include "rt_scene.hpp"
+
+struct rth_bvh {
+    rt::Bvh bvh;
+};
+
+extern "C" {
+
+rth_bvh *rth_bvh_build_subdivide(const rtg_tri *tris, uint64_t n, const double *vertex_normals, int threads) {
+    rth_bvh *b = new rth_bvh();
+    b->bvh = rt::build_subdivide(tris, n, vertex_normals, threads);
+    return b;
+}
+void rth_bvh_destroy(rth_bvh *b) { delete b; }
+void rth_bvh_view(const rth_bvh *b, rtg_bvh *out) { *out = b->bvh.view(); }
+const uint32_t *rth_bvh_leaf_source(const rth_bvh *b) { return b->bvh.leaf_source.data(); }
+uint32_t rth_bvh_depth(const rth_bvh *b) { return b->bvh.depth; }
+
+void rth_heightfield(uint32_t nx, uint32_t ny, uint64_t seed, double scale, rtg_tri *out) {
+    rt::heightfield(nx, ny, seed, scale, out);
+}
+void rth_bench_mesh_rays(const double lo_hi[6], uint64_t n, uint64_t seed, double *rays6) {
+    rt::bench_mesh_rays(lo_hi, n, seed, rays6);
+}
+void rth_sort_rays(const double lo_hi[6], const double *rays6, uint64_t n, uint32_t *perm, double *sorted) {
+    std::vector<uint64_t> keys((size_t)n);
+    for (uint64_t i = 0; i < n; i++) keys[i] = rt::ray_sort_key(lo_hi, rays6 + i * 6);
+    std::iota(perm, perm + n, 0u);
+    std::stable_sort(perm, perm + n, [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+    if (sorted)
+        for (uint64_t i = 0; i < n; i++) std::memcpy(sorted + i * 6, rays6 + (size_t)perm[i] * 6, 6 * sizeof(double));
+}
+
+void rth_transform_build(double scale, const double translate[3], rtg_transform *out) {
+    rt::TransformBuilder tb;
+    tb.scale(scale).translate(translate[0], translate[1], translate[2]);
+    *out = tb.build().t;
+}
+void rth_scene_builder(uint64_t time, rtg_object objects[2], rtg_light lights[2], rtg_view *view) {
+    rt::SceneBuilder sb;
+    sb.time = time;
+    std::vector<rt::Object> objs = sb.scene_object();
+    objects[0] = objs[0].c;
+    objects[1] = objs[1].c;
+    std::vector<rt::Light> ls = sb.lights();
+    for (int i = 0; i < 2; i++) {
+        lights[i].position[0] = ls[i].sphere.orig.x;
+        lights[i].position[1] = ls[i].sphere.orig.y;
+        lights[i].position[2] = ls[i].sphere.orig.z;
+        lights[i].color[0] = ls[i].color.x;
+        lights[i].color[1] = ls[i].color.y;
+        lights[i].color[2] = ls[i].color.z;
+    }
+    *view = sb.view().c();
+}
+int rth_render_scene_builder(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32_t height, uint32_t max_depth,
+                             double *out_rgb, rtg_hit *out_hits) {
+    rt::SceneBuilder sb;
+    sb.time = time;
+    rt::Scene scene = sb.scene();
+    scene.size[0] = width;
+    scene.size[1] = height;
+    rt::Renderer r(ctx, std::move(scene));
+    r.max_depth = max_depth;
+    int rc = r.render();
+    if (rc != RTG_OK) return rc;
+    if (out_rgb) std::memcpy(out_rgb, r.radiosity().data(), r.radiosity().size() * sizeof(double));
+    if (out_hits) std::memcpy(out_hits, r.hits().data(), r.hits().size() * sizeof(rtg_hit));
+    return RTG_OK;
+}
+uint64_t rth_to_hdr(const double *rgb, uint32_t width, uint32_t height, uint8_t *out, uint64_t cap) {
+    std::vector<uint8_t> b = rt::to_hdr(rgb, width, height);
+    if (out && cap >= b.size()) std::memcpy(out, b.data(), b.size());
+    return b.size();
+}
+
+} // extern "C"

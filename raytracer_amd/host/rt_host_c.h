@@ -1,0 +1,40 @@
+/* rt_host_c.h -- C entry points of the host-side library (librt_host.so) for
+ * callers without a C++ toolchain (the Python tests and bench).  Thin wrappers
+ * over rt_bvh.hpp / rt_mesh.hpp / rt_scene.hpp. */
+#ifndef RT_HOST_C_H
+#define RT_HOST_C_H
+#include "../../include/rtg.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rth_bvh rth_bvh;
+
+/* BvhForest::new(tris).subdivide() + Bvh::new (src/tree/bvh_subdivide.rs, src/tree/bvh.rs:80-106) */
+rth_bvh *rth_bvh_build_subdivide(const rtg_tri *tris, uint64_t n, const double *vertex_normals, int threads);
+void rth_bvh_destroy(rth_bvh *b);
+void rth_bvh_view(const rth_bvh *b, rtg_bvh *out);
+const uint32_t *rth_bvh_leaf_source(const rth_bvh *b);
+uint32_t rth_bvh_depth(const rth_bvh *b);
+
+void rth_heightfield(uint32_t nx, uint32_t ny, uint64_t seed, double scale, rtg_tri *out);
+void rth_bench_mesh_rays(const double lo_hi[6], uint64_t n, uint64_t seed, double *rays6);
+/* Stable sort of rays by (direction octant, Morton code of origin); perm[i] = source index of sorted ray i. */
+void rth_sort_rays(const double lo_hi[6], const double *rays6, uint64_t n, uint32_t *perm, double *sorted_rays6);
+
+/* TransformBuilder::new().scale(s).translate(x,y,z).build() (src/geo/transform.rs:33-49) */
+void rth_transform_build(double scale, const double translate[3], rtg_transform *out);
+/* SceneBuilder{time} (src/lib.rs:42-121): objects[2] = sphere, plane; lights[2]; view. */
+void rth_scene_builder(uint64_t time, rtg_object objects[2], rtg_light lights[2], rtg_view *view);
+
+/* Renderer over the default scene plus optional extra mesh objects: renders `width` x `height`
+ * and returns the radiosity (3 doubles per pixel) and primary hits. */
+int rth_render_scene_builder(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32_t height, uint32_t max_depth,
+                             double *out_rgb, rtg_hit *out_hits);
+/* Radiance .hdr bytes of an RGB double image; returns the byte count (call with out == NULL to size). */
+uint64_t rth_to_hdr(const double *rgb, uint32_t width, uint32_t height, uint8_t *out, uint64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,273 @@
+// rt_scene.cpp -- see rt_scene.hpp.
+#include "rt_scene.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace rt {
+
+static const double PI = 3.14159265358979323846264338327950288;
+
+Mat4 Mat4::identity() {
+    Mat4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) r.m[i][j] = i == j ? 1.0 : 0.0;
+    return r;
+}
+Mat4 Mat4::from_scale(Vec3 s) {
+    Mat4 r;
+    std::memset(r.m, 0, sizeof(r.m));   // Mat4::from_mat3(Mat3::from_diagonal(scale))
+    r.m[0][0] = s.x;
+    r.m[1][1] = s.y;
+    r.m[2][2] = s.z;
+    r.m[3][3] = 1.0;
+    return r;
+}
+Mat4 Mat4::from_translation(Vec3 t) {
+    Mat4 r = identity();
+    r.m[0][3] = t.x;
+    r.m[1][3] = t.y;
+    r.m[2][3] = t.z;
+    return r;
+}
+// self applied to every column of rhs; each entry is a dot folded from 0.0.
+Mat4 Mat4::mul(const Mat4 &rhs) const {
+    Mat4 r;
+    for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 4; i++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s = s + m[i][k] * rhs.m[k][j];
+            r.m[i][j] = s;
+        }
+    return r;
+}
+Mat4 Mat4::from_scale_rotation_translation(Vec3 scale, Vec3 translation) {
+    return from_scale(scale).mul(identity()).mul(from_translation(translation));
+}
+
+Transform Transform::from(const Mat4 &forward) {
+    Transform t;
+    rtg_transform_from_forward(&forward.m[0][0], &t.t);
+    return t;
+}
+Transform Transform::default_() { return TransformBuilder().build(); }
+TransformBuilder &TransformBuilder::scale(double amount) {
+    scale_ = Vec3{amount, amount, amount};
+    return *this;
+}
+TransformBuilder &TransformBuilder::translate(double x, double y, double z) {
+    translate_ = Vec3{x, y, z};
+    return *this;
+}
+TransformBuilder &TransformBuilder::rotate() { return *this; }
+Transform TransformBuilder::build() const {
+    return Transform::from(Mat4::from_scale_rotation_translation(scale_, translate_));
+}
+
+rtg_material Material::c() const {
+    rtg_material m;
+    std::memset(&m, 0, sizeof(m));
+    m.diffuse[0] = diffuse.x;
+    m.diffuse[1] = diffuse.y;
+    m.diffuse[2] = diffuse.z;
+    m.has_dielectric = has_dielectric ? 1 : 0;
+    m.n1 = n1;
+    m.n2 = n2;
+    return m;
+}
+
+View View::from_fov(Vec3 orig, double fov_x, double fov_y) {
+    View v;
+    v.orig = orig;
+    v.fov[0] = fov_x;
+    v.fov[1] = fov_y;
+    return v;
+}
+rtg_view View::c() const {
+    rtg_view v;
+    v.orig[0] = orig.x;
+    v.orig[1] = orig.y;
+    v.orig[2] = orig.z;
+    v.tan_half_fov[0] = std::tan(fov[0] / 2.0);   // geo/view.rs:14-15
+    v.tan_half_fov[1] = std::tan(fov[1] / 2.0);
+    return v;
+}
+
+GpuMesh::~GpuMesh() {
+    if (handle) rtg_mesh_destroy(handle);
+}
+std::shared_ptr<GpuMesh> upload_mesh(rtg_ctx *ctx, Bvh bvh) {
+    auto m = std::make_shared<GpuMesh>();
+    m->bvh = std::move(bvh);
+    rtg_bvh v = m->bvh.view();
+    if (rtg_mesh_create(ctx, &v, &m->handle) != RTG_OK) return nullptr;
+    return m;
+}
+
+static void set3(double *d, Vec3 v) {
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+}
+Object Object::sphere(const Transform &t, Sphere s, Material m) {
+    Object o;
+    std::memset(&o.c, 0, sizeof(o.c));
+    o.c.kind = RTG_SPHERE;
+    o.c.transform = t.t;
+    o.c.material = m.c();
+    set3(o.c.sphere_center, s.orig);
+    o.c.sphere_radius = s.rad;
+    return o;
+}
+Object Object::plane(const Transform &t, Vec3 position, Vec3 tan1, Vec3 tan2, Material m1, Material m2) {
+    Object o;
+    std::memset(&o.c, 0, sizeof(o.c));
+    o.c.kind = RTG_PLANE;
+    o.c.transform = t.t;
+    o.c.material = m1.c();
+    o.c.material2 = m2.c();
+    set3(o.c.plane_position, position);
+    set3(o.c.plane_tan1, tan1);
+    set3(o.c.plane_tan2, tan2);
+    return o;
+}
+Object Object::model(const Transform &t, std::shared_ptr<GpuMesh> mesh, Material m) {
+    Object o;
+    std::memset(&o.c, 0, sizeof(o.c));
+    o.c.kind = RTG_MESH;
+    o.c.transform = t.t;
+    o.c.material = m.c();
+    o.c.mesh = mesh ? mesh->handle : nullptr;
+    o.mesh = std::move(mesh);
+    return o;
+}
+
+// ---- lib.rs:42-121 -------------------------------------------------------------
+Material SceneBuilder::material() const {                      // lib.rs:47-49
+    return Material{Color{1.0 * 0.0, 1.0 * 0.0, 1.0 * 0.0}, true, 1.0, 1.5};
+}
+Object SceneBuilder::make_mesh(std::shared_ptr<GpuMesh> mesh, const Transform &t) const {   // lib.rs:50-54
+    return Object::model(t, std::move(mesh), material());
+}
+Object SceneBuilder::sphere() const {                          // lib.rs:68-77
+    return Object::sphere(Transform::default_(), Sphere{Vec3{0.0, -0.2, 0.0}, 0.2},
+                          Material{Color{0.0, 0.0, 0.0}, true, 1.0, 1.5});
+}
+Object SceneBuilder::plane() const {                           // lib.rs:78-86
+    return Object::plane(Transform::from(Mat4::identity()), Vec3{0.0, -0.5, 0.0}, Vec3{0.0, 0.0, -1.0},
+                         Vec3{-1.0, 0.0, 0.0}, Material{Color{1.0, 1.0, 1.0}, false, 0, 0},
+                         Material{Color{0.1, 0.1, 0.1}, false, 0, 0});
+}
+View SceneBuilder::view() const {                              // lib.rs:87-89
+    return View::from_fov(Vec3{0.0, 0.0, 1.0}, PI * 0.5, PI * 0.5);
+}
+std::vector<Light> SceneBuilder::lights() const {              // lib.rs:90-102
+    const double lightz = 1.0, intensity = 100.0, lightdis = 1.0;
+    const double c = std::cos((double)time / 100.0 * PI * 2.0);
+    const double s = std::sin((double)time / 100.0 * PI * 2.0);
+    return {Light{Sphere{Vec3{lightdis * c, lightdis * s, lightz}, 1.0}, Color{0.0, 0.0, intensity}},
+            Light{Sphere{Vec3{-lightdis * c, lightdis * s, lightz}, 1.0}, Color{0.0, intensity, 0.0}}};
+}
+std::vector<Object> SceneBuilder::scene_object() const { return {sphere(), plane()}; }   // lib.rs:103-108
+Scene SceneBuilder::scene() const {                            // lib.rs:109-120
+    Scene s;
+    s.size[0] = 300;
+    s.size[1] = 300;
+    s.view = view();
+    s.lights = lights();
+    s.scene_object = scene_object();
+    s.photon_count = 10000000;
+    s.photon_samples = 3;
+    s.newton_steps = 5;
+    s.newton_epsilon = 0.00001;
+    return s;
+}
+
+// ---- Renderer ---------------------------------------------------------------------
+Renderer::Renderer(rtg_ctx *ctx, Scene scene) : ctx_(ctx), scene_(std::move(scene)) {}
+Renderer::~Renderer() {
+    if (gpu_scene_) rtg_scene_destroy(gpu_scene_);
+}
+const char *Renderer::error() const { return rtg_last_error(ctx_); }
+
+int Renderer::render() {
+    if (!gpu_scene_) {
+        std::vector<rtg_object> objs;
+        for (const Object &o : scene_.scene_object) objs.push_back(o.c);
+        rtg_scene_desc d{objs.data(), (uint32_t)objs.size()};
+        int rc = rtg_scene_create(ctx_, &d, &gpu_scene_);
+        if (rc != RTG_OK) return rc;
+    }
+    const uint32_t w = scene_.size[0], h = scene_.size[1];
+    std::vector<rtg_light> lights;
+    for (const Light &l : scene_.lights) {
+        rtg_light x;
+        set3(x.position, l.sphere.orig);
+        set3(x.color, l.color);
+        lights.push_back(x);
+    }
+    rgb_.assign((size_t)w * h * 3, 0.0);
+    hits_.assign((size_t)w * h, rtg_hit{RTG_NONE, RTG_NONE, 0.0});
+    rtg_view v = scene_.view.c();
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = rtg_render_frame(gpu_scene_, &v, lights.data(), (uint32_t)lights.size(), w, h, rtg_rect{0, 0, w, h},
+                              max_depth, rgb_.data(), nullptr, hits_.data());
+    seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+double smpte2048_encode(double x) {
+    const double M1 = 1305.0 / 8192.0, M2 = 2523.0 / 32.0;
+    const double C1 = 107.0 / 128.0, C2 = 2413.0 / 128.0, C3 = 2392.0 / 128.0;
+    return std::pow((C1 + C2 * std::pow(x, M1)) / (1.0 + C3 * std::pow(x, M1)), M2);
+}
+
+// Flat (run-length-free) Radiance picture: legal for every reader; the pixel
+// conversion is the shared-exponent RGBE of the `image` crate's HdrEncoder
+// that the reference calls (render/image.rs:63-64).
+std::vector<uint8_t> to_hdr(const double *rgb, uint32_t width, uint32_t height) {
+    std::string head = "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y " + std::to_string(height) + " +X " + std::to_string(width) + "\n";
+    std::vector<uint8_t> out(head.begin(), head.end());
+    out.reserve(out.size() + (size_t)width * height * 4);
+    for (uint32_t y = 0; y < height; y++)
+        for (uint32_t x = 0; x < width; x++) {
+            const double *p = rgb + ((size_t)y * width + x) * 3;
+            double c[3] = {p[0], p[1], p[2]};
+            if (c[0] != c[0] || c[1] != c[1] || c[2] != c[2]) {      // image.rs:52-58
+                double v = ((x + y) % 2 == 0) ? 0.0 : 1.0;
+                c[0] = c[1] = c[2] = v;
+            }
+            float f[3] = {(float)c[0], (float)c[1], (float)c[2]};
+            float mx = std::fmax(f[0], std::fmax(f[1], f[2]));
+            uint8_t px[4] = {0, 0, 0, 0};
+            if (mx > 0.0f) {
+                int e = (int)std::floor(std::log2(mx)) + 1;
+                float mul = std::ldexp(1.0f, e);
+                for (int k = 0; k < 3; k++) {
+                    float q = std::trunc(f[k] / mul * 256.0f);
+                    px[k] = (uint8_t)(q < 0.0f ? 0.0f : (q > 255.0f ? 255.0f : q));
+                }
+                px[3] = (uint8_t)(e + 128);
+            }
+            out.insert(out.end(), px, px + 4);
+        }
+    return out;
+}
+
+std::map<std::string, std::vector<uint8_t>> Renderer::images() const {      // renderer.rs:379-385
+    std::map<std::string, std::vector<uint8_t>> r;
+    const uint32_t w = scene_.size[0], h = scene_.size[1];
+    if (rgb_.empty()) return r;
+    r["image.hdr"] = to_hdr(rgb_.data(), w, h);
+    std::vector<double> pq(rgb_.size());
+    for (size_t i = 0; i < rgb_.size(); i++) pq[i] = smpte2048_encode(rgb_[i] / 80.0);    // image.rs:39
+    r["image.pq.hdr"] = to_hdr(pq.data(), w, h);
+    // The reference's perf image is per-pixel CPU time x 3000; a GPU frame has one
+    // time for all pixels, spread evenly.
+    std::vector<double> perf(rgb_.size(), seconds_ / ((double)w * h) * 3000.0);
+    r["perf.hdr"] = to_hdr(perf.data(), w, h);
+    return r;
+}
+
+} // namespace rt

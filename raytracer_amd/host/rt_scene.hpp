@@ -1,0 +1,144 @@
+// rt_scene.hpp -- host-side scene description and frame API over the C ABI.
+//
+// C++ stand-in for the Rust host code that stays on the CPU: it keeps the
+// reference's names and argument meaning (SceneBuilder, Scene, Renderer,
+// TransformBuilder, View, Light, Material, SphereObject, PlaneObject,
+// MeshObject) so a port of the reference's bins reads the same, and drives the
+// GPU only through include/rtg.h.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rtg.h"
+#include "rt_bvh.hpp"
+
+namespace rt {
+
+struct Vec3 {
+    double x = 0, y = 0, z = 0;
+};
+using Color = Vec3;
+
+struct Mat4 {
+    double m[4][4];
+    static Mat4 identity();
+    static Mat4 from_scale(Vec3 s);                       // math/mat.rs:161-163
+    static Mat4 from_translation(Vec3 t);                 // math/mat.rs:165-171
+    static Mat4 from_scale_rotation_translation(Vec3 scale, Vec3 translation);   // math/mat.rs:172-177 (R = I)
+    Mat4 mul(const Mat4 &rhs) const;                      // math/mat.rs:185-190
+};
+
+// geo/transform.rs:8-58
+struct Transform {
+    rtg_transform t;
+    static Transform from(const Mat4 &forward);
+    static Transform default_();
+};
+struct TransformBuilder {
+    Vec3 translate_{0, 0, 0}, scale_{1, 1, 1};
+    TransformBuilder &scale(double amount);
+    TransformBuilder &translate(double x, double y, double z);
+    TransformBuilder &rotate();
+    Transform build() const;
+};
+
+// render/material.rs:3-7
+struct Material {
+    Color diffuse;
+    bool has_dielectric = false;
+    double n1 = 0, n2 = 0;
+    rtg_material c() const;
+};
+
+// geo/view.rs:6-12
+struct View {
+    Vec3 orig;
+    double fov[2];
+    static View from_fov(Vec3 orig, double fov_x, double fov_y);
+    rtg_view c() const;   // evaluates tan(fov/2) with the host libm
+};
+
+// geo/sphere.rs:14-17, render/renderer.rs:38-42
+struct Sphere {
+    Vec3 orig;
+    double rad = 0;
+};
+struct Light {
+    Sphere sphere;
+    Color color;
+};
+
+// A mesh resident on one GPU: the `Arc<Bvh>` of render/mesh_object.rs:10-13.
+struct GpuMesh {
+    rtg_mesh *handle = nullptr;
+    Bvh bvh;
+    ~GpuMesh();
+};
+
+// One TransformObject<AnyObject> (render/transform_object.rs, any_object.rs).
+struct Object {
+    rtg_object c{};
+    std::shared_ptr<GpuMesh> mesh;
+    static Object sphere(const Transform &t, Sphere s, Material m);                          // SphereObject::new
+    static Object plane(const Transform &t, Vec3 position, Vec3 tan1, Vec3 tan2, Material m1, Material m2);  // PlaneObject::new
+    static Object model(const Transform &t, std::shared_ptr<GpuMesh> mesh, Material m);      // MeshObject::new
+};
+
+// render/renderer.rs:44-53.  The photon fields are carried for interface
+// parity; the GPU path renders the direct + specular terms only.
+struct Scene {
+    uint32_t size[2] = {300, 300};
+    View view;
+    std::vector<Light> lights;
+    std::vector<Object> scene_object;
+    uint64_t photon_count = 0;
+    uint32_t photon_samples = 0;
+    uint32_t newton_steps = 0;
+    double newton_epsilon = 0;
+};
+
+// lib.rs:42-121
+struct SceneBuilder {
+    uint64_t time = 0;
+    Material material() const;
+    Object sphere() const;
+    Object plane() const;
+    View view() const;
+    std::vector<Light> lights() const;
+    std::vector<Object> scene_object() const;
+    Scene scene() const;
+    Object make_mesh(std::shared_ptr<GpuMesh> mesh, const Transform &t) const;
+};
+
+// render/renderer.rs:55-61,105-154,379-385
+class Renderer {
+  public:
+    Renderer(rtg_ctx *ctx, Scene scene);          // Renderer::new
+    ~Renderer();
+    int render();                                 // Renderer::render: the pixel pass on the GPU
+    std::map<std::string, std::vector<uint8_t>> images() const;   // image.hdr, image.pq.hdr, perf.hdr
+    const std::vector<double> &radiosity() const { return rgb_; }
+    const std::vector<rtg_hit> &hits() const { return hits_; }
+    const char *error() const;
+    uint32_t max_depth = 4;                       // renderer.rs:312
+
+  private:
+    rtg_ctx *ctx_;
+    Scene scene_;
+    rtg_scene *gpu_scene_ = nullptr;
+    std::vector<double> rgb_;
+    std::vector<rtg_hit> hits_;
+    double seconds_ = 0;
+};
+
+std::shared_ptr<GpuMesh> upload_mesh(rtg_ctx *ctx, Bvh bvh);
+
+// Radiance RGBE (.hdr) writer for a row-major RGB double image; NaN pixels
+// become the reference's checkerboard (render/image.rs:44-66).
+std::vector<uint8_t> to_hdr(const double *rgb, uint32_t width, uint32_t height);
+double smpte2048_encode(double x);   // geo/color.rs:15-17
+
+} // namespace rt

@@ -1,0 +1,489 @@
+"""ctypes binding of include/rtg.h (librtg.so) and of the host library (librt_host.so).
+
+Only plain pointers and sizes cross the boundary.  Arrays are numpy arrays
+(host memory) or raw device addresses (ints, e.g. ``torch.Tensor.data_ptr()``).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+RTG_NONE = 0xFFFFFFFF
+SPHERE, MESH, PLANE, PATCHES = 0, 1, 2, 3
+
+
+def _load(name):
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the ray-cast path)")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+lib = _load("librtg.so")
+host = _load("librt_host.so")
+
+
+# ---- PODs of include/rtg.h -------------------------------------------------
+class BvhNode(C.Structure):
+    _fields_ = [("lo", C.c_double * 3), ("hi", C.c_double * 3), ("child_begin", C.c_uint32),
+                ("child_end", C.c_uint32), ("leaf_begin", C.c_uint32), ("leaf_end", C.c_uint32)]
+
+
+class Bvh(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_uint64), ("leaves", C.c_void_p), ("n_leaves", C.c_uint64),
+                ("vertex_normals", C.c_void_p), ("root", C.c_uint32)]
+
+
+class Material(C.Structure):
+    _fields_ = [("diffuse", C.c_double * 3), ("n1", C.c_double), ("n2", C.c_double), ("has_dielectric", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+class Transform(C.Structure):
+    _fields_ = [("forward", C.c_double * 16), ("reverse", C.c_double * 16), ("forward_norm", C.c_double * 9)]
+
+
+class Object(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("transform", Transform), ("material", Material),
+                ("material2", Material), ("sphere_center", C.c_double * 3), ("sphere_radius", C.c_double),
+                ("plane_position", C.c_double * 3), ("plane_tan1", C.c_double * 3), ("plane_tan2", C.c_double * 3),
+                ("mesh", C.c_void_p)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("objects", C.POINTER(Object)), ("n_objects", C.c_uint32)]
+
+
+class View(C.Structure):
+    _fields_ = [("orig", C.c_double * 3), ("tan_half_fov", C.c_double * 2)]
+
+
+class Light(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("color", C.c_double * 3)]
+
+
+class Rect(C.Structure):
+    _fields_ = [("x0", C.c_uint32), ("y0", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32)]
+
+
+NODE_DTYPE = np.dtype([("lo", "<f8", 3), ("hi", "<f8", 3), ("child_begin", "<u4"), ("child_end", "<u4"),
+                       ("leaf_begin", "<u4"), ("leaf_end", "<u4")])
+HIT_DTYPE = np.dtype([("object", "<u4"), ("leaf", "<u4"), ("t", "<f8")])
+POINT_DTYPE = np.dtype([("time", "<f8"), ("position", "<f8", 3), ("inter_normal", "<f8", 3),
+                        ("geo_normal", "<f8", 3), ("manifold_point", "<f8", 2), ("manifold", "<u4", 2),
+                        ("manifold_len", "<u4"), ("material_slot", "<u4")])
+COUNTER_DTYPE = np.dtype([("nodes_visited", "<u4"), ("tris_tested", "<u4")])
+LIGHT_DTYPE = np.dtype([("position", "<f8", 3), ("color", "<f8", 3)])
+assert NODE_DTYPE.itemsize == 64 and HIT_DTYPE.itemsize == 16 and POINT_DTYPE.itemsize == 112
+assert C.sizeof(BvhNode) == 64 and C.sizeof(Transform) == 328 and C.sizeof(Material) == 48
+
+
+class RtgError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"rtg error {code}: {message}")
+        self.code = code
+
+
+def _sig(fn, restype, *argtypes):
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+
+
+_vp = C.c_void_p
+_sig(lib.rtg_version, C.c_char_p)
+_sig(lib.rtg_ctx_create, C.c_int, C.c_int, C.POINTER(_vp))
+_sig(lib.rtg_ctx_destroy, None, _vp)
+_sig(lib.rtg_last_error, C.c_char_p, _vp)
+_sig(lib.rtg_ctx_set_stream, C.c_int, _vp, _vp)
+_sig(lib.rtg_ctx_get_stream, _vp, _vp)
+_sig(lib.rtg_ctx_synchronize, C.c_int, _vp)
+_sig(lib.rtg_ctx_set_option, C.c_int, _vp, C.c_char_p, C.c_int64)
+_sig(lib.rtg_transform_from_forward, C.c_int, C.POINTER(C.c_double), C.POINTER(Transform))
+_sig(lib.rtg_mesh_create, C.c_int, _vp, C.POINTER(Bvh), C.POINTER(_vp))
+_sig(lib.rtg_mesh_destroy, None, _vp)
+_sig(lib.rtg_mesh_bounds, C.c_int, _vp, C.POINTER(C.c_double))
+_sig(lib.rtg_scene_create, C.c_int, _vp, C.POINTER(SceneDesc), C.POINTER(_vp))
+_sig(lib.rtg_scene_destroy, None, _vp)
+_sig(lib.rtg_render_primary, C.c_int, _vp, C.POINTER(View), C.c_uint32, C.c_uint32, Rect, _vp, _vp, _vp)
+_sig(lib.rtg_trace, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp, _vp)
+_sig(lib.rtg_shade_direct, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, _vp, _vp)
+_sig(lib.rtg_render_frame, C.c_int, _vp, C.POINTER(View), _vp, C.c_uint32, C.c_uint32, C.c_uint32, Rect,
+     C.c_uint32, _vp, _vp, _vp)
+
+_sig(host.rth_bvh_build_subdivide, _vp, _vp, C.c_uint64, _vp, C.c_int)
+_sig(host.rth_bvh_destroy, None, _vp)
+_sig(host.rth_bvh_view, None, _vp, C.POINTER(Bvh))
+_sig(host.rth_bvh_leaf_source, C.POINTER(C.c_uint32), _vp)
+_sig(host.rth_bvh_depth, C.c_uint32, _vp)
+_sig(host.rth_heightfield, None, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, _vp)
+_sig(host.rth_bench_mesh_rays, None, C.POINTER(C.c_double), C.c_uint64, C.c_uint64, _vp)
+_sig(host.rth_sort_rays, None, C.POINTER(C.c_double), _vp, C.c_uint64, _vp, _vp)
+_sig(host.rth_transform_build, None, C.c_double, C.POINTER(C.c_double), C.POINTER(Transform))
+_sig(host.rth_scene_builder, None, C.c_uint64, C.POINTER(Object), C.POINTER(Light), C.POINTER(View))
+_sig(host.rth_render_scene_builder, C.c_int, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp)
+_sig(host.rth_to_hdr, C.c_uint64, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64)
+
+
+def _ptr(a):
+    """Device address (int), numpy array, or None -> void*."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return C.c_void_p(a.ctypes.data)
+    raise TypeError(f"unsupported buffer {type(a)}")
+
+
+def version():
+    return lib.rtg_version().decode()
+
+
+# ---- host library helpers -----------------------------------------------------
+def heightfield(nx, ny, seed=1, scale=1.0):
+    """Synthetic terrain mesh: (2*nx*ny, 3, 3) float64 triangle array."""
+    tris = np.empty((2 * nx * ny, 3, 3), dtype=np.float64)
+    host.rth_heightfield(nx, ny, seed, float(scale), _ptr(tris))
+    return tris
+
+
+def bench_mesh_rays(lo_hi, n, seed=10212233):
+    b = (C.c_double * 6)(*[float(x) for x in lo_hi])
+    rays = np.empty((n, 6), dtype=np.float64)
+    host.rth_bench_mesh_rays(b, n, seed, _ptr(rays))
+    return rays
+
+
+def sort_rays(lo_hi, rays):
+    b = (C.c_double * 6)(*[float(x) for x in lo_hi])
+    n = rays.shape[0]
+    perm = np.empty(n, dtype=np.uint32)
+    out = np.empty_like(rays)
+    host.rth_sort_rays(b, _ptr(rays), n, _ptr(perm), _ptr(out))
+    return perm, out
+
+
+def transform(scale=1.0, translate=(0.0, 0.0, 0.0)):
+    t = Transform()
+    host.rth_transform_build(float(scale), (C.c_double * 3)(*translate), C.byref(t))
+    return t
+
+
+def transform_from_forward(forward16):
+    t = Transform()
+    f = (C.c_double * 16)(*[float(x) for x in np.asarray(forward16).reshape(16)])
+    rc = lib.rtg_transform_from_forward(f, C.byref(t))
+    if rc != 0:
+        raise RtgError(rc, "rtg_transform_from_forward")
+    return t
+
+
+def material(diffuse=(0.0, 0.0, 0.0), dielectric=None):
+    m = Material()
+    m.diffuse[:] = diffuse
+    if dielectric is not None:
+        m.has_dielectric = 1
+        m.n1, m.n2 = dielectric
+    return m
+
+
+def scene_builder(time=0):
+    """SceneBuilder{time}: ([sphere, plane] objects, [2 lights] as LIGHT_DTYPE array, View)."""
+    objs = (Object * 2)()
+    lights = (Light * 2)()
+    view = View()
+    host.rth_scene_builder(time, objs, lights, C.byref(view))
+    la = np.zeros(2, dtype=LIGHT_DTYPE)
+    for i in range(2):
+        la[i]["position"] = list(lights[i].position)
+        la[i]["color"] = list(lights[i].color)
+    return [objs[0], objs[1]], la, view
+
+
+def copy_object(o):
+    c = Object()
+    C.memmove(C.byref(c), C.byref(o), C.sizeof(Object))
+    return c
+
+
+class HostBvh:
+    """BvhForest::new(tris).subdivide() + Bvh::new -- flattened on the host."""
+    _h = None
+
+    def __init__(self, tris, vertex_normals=None, threads=0):
+        tris = np.ascontiguousarray(tris, dtype=np.float64).reshape(-1, 3, 3)
+        self._tris = tris
+        self._normals = None if vertex_normals is None else np.ascontiguousarray(vertex_normals, dtype=np.float64)
+        self._h = host.rth_bvh_build_subdivide(_ptr(tris), tris.shape[0], _ptr(self._normals), threads)
+        self.view = Bvh()
+        host.rth_bvh_view(self._h, C.byref(self.view))
+
+    @property
+    def n_nodes(self):
+        return int(self.view.n_nodes)
+
+    @property
+    def n_leaves(self):
+        return int(self.view.n_leaves)
+
+    @property
+    def root(self):
+        return int(self.view.root)
+
+    @property
+    def depth(self):
+        return int(host.rth_bvh_depth(self._h))
+
+    def nodes(self):
+        buf = (C.c_char * (self.n_nodes * 64)).from_address(self.view.nodes)
+        return np.frombuffer(buf, dtype=NODE_DTYPE).copy()
+
+    def leaves(self):
+        if self.n_leaves == 0:
+            return np.zeros((0, 3, 3))
+        buf = (C.c_char * (self.n_leaves * 72)).from_address(self.view.leaves)
+        return np.frombuffer(buf, dtype=np.float64).reshape(-1, 3, 3).copy()
+
+    def leaf_source(self):
+        p = host.rth_bvh_leaf_source(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.n_leaves,)).copy() if self.n_leaves else np.zeros(0, np.uint32)
+
+    def bounds(self):
+        n = self.nodes()[self.root]
+        return np.concatenate([n["lo"], n["hi"]])
+
+    def close(self):
+        if self._h:
+            host.rth_bvh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def flat_bvh(nodes, leaves, root, vertex_normals=None):
+    """Wrap caller-flattened arrays (NODE_DTYPE nodes, (n,3,3) leaves) as an rtg_bvh; keeps references."""
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    leaves = np.ascontiguousarray(leaves, dtype=np.float64).reshape(-1, 3, 3)
+    v = Bvh()
+    v.nodes = nodes.ctypes.data if nodes.size else None
+    v.n_nodes = nodes.shape[0]
+    v.leaves = leaves.ctypes.data if leaves.size else None
+    v.n_leaves = leaves.shape[0]
+    if vertex_normals is not None:
+        vertex_normals = np.ascontiguousarray(vertex_normals, dtype=np.float64)
+        v.vertex_normals = vertex_normals.ctypes.data
+    v.root = root
+    v._keep = (nodes, leaves, vertex_normals)
+    return v
+
+
+# ---- the GPU path ----------------------------------------------------------------
+class Context:
+    _h = None
+
+    def __init__(self, device=0):
+        h = _vp()
+        rc = lib.rtg_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise RtgError(rc, lib.rtg_last_error(None).decode())
+        self._h = h
+        self.device = device
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtgError(rc, lib.rtg_last_error(self._h).decode())
+
+    def set_option(self, key, value):
+        self._check(lib.rtg_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def set_stream(self, stream_handle):
+        self._check(lib.rtg_ctx_set_stream(self._h, C.c_void_p(stream_handle) if stream_handle else None))
+
+    @property
+    def stream(self):
+        return lib.rtg_ctx_get_stream(self._h) or 0
+
+    def synchronize(self):
+        self._check(lib.rtg_ctx_synchronize(self._h))
+
+    def mesh(self, bvh):
+        return Mesh(self, bvh)
+
+    def scene(self, objects):
+        return Scene(self, objects)
+
+    def close(self):
+        if self._h:
+            lib.rtg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Mesh:
+    _h = None
+
+    def __init__(self, ctx, bvh):
+        view = bvh.view if isinstance(bvh, HostBvh) else bvh
+        h = _vp()
+        ctx._check(lib.rtg_mesh_create(ctx._h, C.byref(view), C.byref(h)))
+        self._h = h
+        self.ctx = ctx
+
+    @property
+    def handle(self):
+        return self._h.value
+
+    def bounds(self):
+        out = (C.c_double * 6)()
+        self.ctx._check(lib.rtg_mesh_bounds(self._h, out))
+        return np.array(list(out))
+
+    def close(self):
+        if self._h:
+            lib.rtg_mesh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def sphere_object(center, radius, mat, xform=None):
+    o = Object()
+    o.kind = SPHERE
+    o.transform = xform if xform is not None else transform()
+    o.material = mat
+    o.sphere_center[:] = center
+    o.sphere_radius = radius
+    return o
+
+
+def plane_object(position, tan1, tan2, mat1, mat2, xform=None):
+    o = Object()
+    o.kind = PLANE
+    o.transform = xform if xform is not None else transform()
+    o.material = mat1
+    o.material2 = mat2
+    o.plane_position[:] = position
+    o.plane_tan1[:] = tan1
+    o.plane_tan2[:] = tan2
+    return o
+
+
+def mesh_object(mesh, mat, xform=None):
+    o = Object()
+    o.kind = MESH
+    o.transform = xform if xform is not None else transform()
+    o.material = mat
+    o.mesh = mesh.handle if isinstance(mesh, Mesh) else mesh
+    o._keep = mesh
+    return o
+
+
+class Scene:
+    _h = None
+
+    def __init__(self, ctx, objects):
+        self.ctx = ctx
+        self._objects = list(objects)
+        arr = (Object * max(1, len(objects)))()
+        for i, o in enumerate(objects):
+            C.memmove(C.byref(arr[i]), C.byref(o), C.sizeof(Object))
+        desc = SceneDesc(arr, len(objects))
+        h = _vp()
+        ctx._check(lib.rtg_scene_create(ctx._h, C.byref(desc), C.byref(h)))
+        self._h = h
+
+    def render_primary(self, view, width, height, tile=None, points=False, counters=False, out_hits=None):
+        """Host-buffer convenience: returns (hits, points|None, counters|None) as numpy arrays over the tile."""
+        x0, y0, w, h = tile if tile is not None else (0, 0, width, height)
+        n = w * h
+        hits = np.empty(n, dtype=HIT_DTYPE) if out_hits is None else out_hits
+        pts = np.empty(n, dtype=POINT_DTYPE) if points else None
+        ctr = np.empty(n, dtype=COUNTER_DTYPE) if counters else None
+        self.ctx._check(lib.rtg_render_primary(self._h, C.byref(view), width, height, Rect(x0, y0, w, h),
+                                               _ptr(hits), _ptr(pts), _ptr(ctr)))
+        return hits, pts, ctr
+
+    def render_primary_raw(self, view, width, height, tile, hits_ptr, points_ptr=None, counters_ptr=None):
+        """Raw pointers (device addresses or numpy arrays); asynchronous for device pointers."""
+        self.ctx._check(lib.rtg_render_primary(self._h, C.byref(view), width, height, Rect(*tile),
+                                               _ptr(hits_ptr), _ptr(points_ptr), _ptr(counters_ptr)))
+
+    def trace(self, rays6, points=False, counters=False):
+        rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
+        n = rays6.shape[0]
+        hits = np.empty(n, dtype=HIT_DTYPE)
+        pts = np.empty(n, dtype=POINT_DTYPE) if points else None
+        ctr = np.empty(n, dtype=COUNTER_DTYPE) if counters else None
+        self.ctx._check(lib.rtg_trace(self._h, _ptr(rays6), n, _ptr(hits), _ptr(pts), _ptr(ctr)))
+        return hits, pts, ctr
+
+    def trace_raw(self, rays_ptr, n, hits_ptr, points_ptr=None, counters_ptr=None):
+        self.ctx._check(lib.rtg_trace(self._h, _ptr(rays_ptr), n, _ptr(hits_ptr), _ptr(points_ptr), _ptr(counters_ptr)))
+
+    def shade_direct(self, lights, points, rgba8=False):
+        lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+        points = np.ascontiguousarray(points, dtype=POINT_DTYPE)
+        n = points.shape[0]
+        rgb = np.empty((n, 3), dtype=np.float64)
+        c8 = np.empty((n, 4), dtype=np.uint8) if rgba8 else None
+        self.ctx._check(lib.rtg_shade_direct(self._h, _ptr(lights), lights.shape[0], _ptr(points), n, _ptr(rgb), _ptr(c8)))
+        return rgb, c8
+
+    def render_frame(self, view, lights, width, height, tile=None, max_depth=4, rgba8=True, hits=True):
+        lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+        x0, y0, w, h = tile if tile is not None else (0, 0, width, height)
+        n = w * h
+        rgb = np.empty((n, 3), dtype=np.float64)
+        c8 = np.empty((n, 4), dtype=np.uint8) if rgba8 else None
+        hh = np.empty(n, dtype=HIT_DTYPE) if hits else None
+        self.ctx._check(lib.rtg_render_frame(self._h, C.byref(view), _ptr(lights), lights.shape[0], width, height,
+                                             Rect(x0, y0, w, h), max_depth, _ptr(rgb), _ptr(c8), _ptr(hh)))
+        return rgb, c8, hh
+
+    def render_frame_raw(self, view, lights_ptr, n_lights, width, height, tile, max_depth, rgb_ptr, rgba8_ptr, hits_ptr):
+        self.ctx._check(lib.rtg_render_frame(self._h, C.byref(view), _ptr(lights_ptr), n_lights, width, height,
+                                             Rect(*tile), max_depth, _ptr(rgb_ptr), _ptr(rgba8_ptr), _ptr(hits_ptr)))
+
+    def close(self):
+        if self._h:
+            lib.rtg_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def make_view(orig=(0.0, 0.0, 1.0), fov=(np.pi * 0.5, np.pi * 0.5)):
+    """View::from_fov with tan(fov/2) evaluated on the host."""
+    import math
+    v = View()
+    v.orig[:] = orig
+    v.tan_half_fov[0] = math.tan(fov[0] / 2.0)
+    v.tan_half_fov[1] = math.tan(fov[1] / 2.0)
+    return v
+
+
+def render_scene_builder(ctx, time, width, height, max_depth=4):
+    """Renderer::new(SceneBuilder{time}.scene()).render() at width x height (C++ host path)."""
+    rgb = np.empty((height * width, 3), dtype=np.float64)
+    hits = np.empty(height * width, dtype=HIT_DTYPE)
+    ctx._check(host.rth_render_scene_builder(ctx._h, time, width, height, max_depth, _ptr(rgb), _ptr(hits)))
+    return rgb, hits
+
+
+def to_hdr(rgb, width, height):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    n = host.rth_to_hdr(_ptr(rgb), width, height, None, 0)
+    out = np.empty(n, dtype=np.uint8)
+    host.rth_to_hdr(_ptr(rgb), width, height, _ptr(out), n)
+    return out.tobytes()

@@ -1,0 +1,279 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracer_amd import rtg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+if not os.path.exists(_SO):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+lib = C.CDLL(_SO)
+
+_vp = C.c_void_p
+_dp = C.POINTER(C.c_double)
+
+
+def _sig(fn, restype, *argtypes):
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+
+
+_sig(lib.orc_minimum, C.c_double, C.c_double, C.c_double)
+_sig(lib.orc_maximum, C.c_double, C.c_double, C.c_double)
+_sig(lib.orc_real_cmp, C.c_int, C.c_double, C.c_double)
+_sig(lib.orc_dot3, C.c_double, _dp, _dp)
+_sig(lib.orc_cross, None, _dp, _dp, _dp)
+_sig(lib.orc_normalize3, None, _dp, _dp)
+for _n in ("orc_mat2_inverse", "orc_mat3_inverse", "orc_mat4_inverse"):
+    _sig(getattr(lib, _n), None, _dp, _dp)
+for _n in ("orc_mat2_mul", "orc_mat3_mul", "orc_mat4_mul"):
+    _sig(getattr(lib, _n), None, _dp, _dp, _dp)
+_sig(lib.orc_mat4_from_scale_rotation_translation, None, _dp, _dp, _dp)
+_sig(lib.orc_transform_from_forward, None, _dp, C.POINTER(rtg.Transform))
+_sig(lib.orc_bounds_union, None, _dp, _dp, _dp)
+_sig(lib.orc_bounds_surface_area, C.c_double, _dp)
+_sig(lib.orc_smpte2048_encode, C.c_double, C.c_double)
+_sig(lib.orc_smpte2048_decode, C.c_double, C.c_double)
+_sig(lib.orc_pq8, C.c_uint8, C.c_double)
+_sig(lib.orc_find_roots_quadratic, C.c_int, C.c_double, C.c_double, C.c_double, _dp)
+_sig(lib.orc_bounds_raycast, C.c_int, _dp, _dp, _dp)
+_sig(lib.orc_triangle_raycast, C.c_int, _dp, _dp, C.c_int, _dp)
+_sig(lib.orc_sphere_raycast, C.c_int, _dp, C.c_double, _dp, _vp)
+_sig(lib.orc_plane_raycast, C.c_int, _dp, _dp, _dp, _dp, _vp, C.POINTER(C.c_int))
+_sig(lib.orc_view_get_ray, None, C.POINTER(rtg.View), _dp, _dp)
+_sig(lib.orc_pixel_ndc, None, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _dp)
+_sig(lib.orc_dielectric, None, _dp, _dp, C.c_double, C.c_double, _dp)
+_sig(lib.orc_bvh_build_subdivide, _vp, _vp, C.c_uint64, _vp)
+_sig(lib.orc_bvh_from_flat, _vp, C.POINTER(rtg.Bvh))
+_sig(lib.orc_bvh_destroy, None, _vp)
+_sig(lib.orc_bvh_n_nodes, C.c_uint64, _vp)
+_sig(lib.orc_bvh_n_leaves, C.c_uint64, _vp)
+_sig(lib.orc_bvh_root, C.c_uint32, _vp)
+_sig(lib.orc_bvh_nodes, _vp, _vp)
+_sig(lib.orc_bvh_leaves, _vp, _vp)
+_sig(lib.orc_bvh_vertex_normals, _vp, _vp)
+_sig(lib.orc_bvh_leaf_source, C.POINTER(C.c_uint32), _vp)
+_sig(lib.orc_bvh_depth, C.c_uint32, _vp)
+_sig(lib.orc_bvh_raycast, C.c_int, _vp, _dp, _vp, _vp)
+_sig(lib.orc_bvh_raycast_brute, C.c_int, _vp, _dp, _vp)
+_sig(lib.orc_scene_create, _vp, C.POINTER(rtg.SceneDesc))
+_sig(lib.orc_scene_destroy, None, _vp)
+_sig(lib.orc_render_primary, C.c_int, _vp, C.POINTER(rtg.View), C.c_uint32, C.c_uint32, rtg.Rect, _vp, _vp, _vp, C.c_int)
+_sig(lib.orc_trace, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_int)
+_sig(lib.orc_shade_direct, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, _vp, _vp, C.c_int)
+_sig(lib.orc_render_frame, C.c_int, _vp, C.POINTER(rtg.View), _vp, C.c_uint32, C.c_uint32, C.c_uint32, rtg.Rect,
+     C.c_uint32, _vp, _vp, _vp, C.c_int)
+
+THREADS = min(8, os.cpu_count() or 1)
+
+
+def d(*vals):
+    vals = [float(v) for v in np.asarray(vals, dtype=np.float64).reshape(-1)]
+    return (C.c_double * len(vals))(*vals)
+
+
+def mat_inverse(m):
+    m = np.asarray(m, dtype=np.float64)
+    n = m.shape[0]
+    out = (C.c_double * (n * n))()
+    getattr(lib, f"orc_mat{n}_inverse")(d(m), out)
+    return np.array(list(out)).reshape(n, n)
+
+
+def mat_mul(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    n = a.shape[0]
+    out = (C.c_double * (n * n))()
+    getattr(lib, f"orc_mat{n}_mul")(d(a), d(b), out)
+    return np.array(list(out)).reshape(n, n)
+
+
+def bounds_raycast(box, ray):
+    out = (C.c_double * 2)()
+    ok = lib.orc_bounds_raycast(d(box), d(ray), out)
+    return (out[0], out[1]) if ok else None
+
+
+def triangle_raycast(tri, ray, manifold=False):
+    out = (C.c_double * 12)()
+    ok = lib.orc_triangle_raycast(d(tri), d(ray), 1 if manifold else 0, out)
+    if not ok:
+        return None
+    o = list(out)
+    return {"t": o[0], "bary": o[1:4], "q": o[4:7], "mp": o[7:9], "n": o[9:12]}
+
+
+def sphere_raycast(center, radius, ray):
+    pt = np.zeros(1, dtype=rtg.POINT_DTYPE)
+    ok = lib.orc_sphere_raycast(d(center), float(radius), d(ray), pt.ctypes.data)
+    return pt[0] if ok else None
+
+
+def plane_raycast(position, tan1, tan2, ray):
+    pt = np.zeros(1, dtype=rtg.POINT_DTYPE)
+    m2 = C.c_int(0)
+    ok = lib.orc_plane_raycast(d(position), d(tan1), d(tan2), d(ray), pt.ctypes.data, C.byref(m2))
+    return (pt[0], bool(m2.value)) if ok else None
+
+
+def find_roots_quadratic(a2, a1, a0):
+    out = (C.c_double * 2)()
+    n = lib.orc_find_roots_quadratic(a2, a1, a0, out)
+    return [out[i] for i in range(n)]
+
+
+def dielectric(inc, signed_norm, n1, n2):
+    out = (C.c_double * 8)()
+    lib.orc_dielectric(d(inc), d(signed_norm), n1, n2, out)
+    o = list(out)
+    return {"reflectance": o[0], "reflect": o[1:4], "has_refract": o[4] != 0.0, "refract": o[5:8]}
+
+
+class OracleBvh:
+    _h = None
+
+    def __init__(self, tris=None, vertex_normals=None, flat=None):
+        if flat is not None:
+            self._keep = flat
+            self._h = lib.orc_bvh_from_flat(C.byref(flat))
+        else:
+            tris = np.ascontiguousarray(tris, dtype=np.float64).reshape(-1, 3, 3)
+            vn = None if vertex_normals is None else np.ascontiguousarray(vertex_normals, dtype=np.float64)
+            self._h = lib.orc_bvh_build_subdivide(tris.ctypes.data, tris.shape[0], None if vn is None else vn.ctypes.data)
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def n_nodes(self):
+        return int(lib.orc_bvh_n_nodes(self._h))
+
+    @property
+    def n_leaves(self):
+        return int(lib.orc_bvh_n_leaves(self._h))
+
+    @property
+    def root(self):
+        return int(lib.orc_bvh_root(self._h))
+
+    @property
+    def depth(self):
+        return int(lib.orc_bvh_depth(self._h))
+
+    def nodes(self):
+        buf = (C.c_char * (self.n_nodes * 64)).from_address(lib.orc_bvh_nodes(self._h))
+        return np.frombuffer(buf, dtype=rtg.NODE_DTYPE).copy()
+
+    def leaves(self):
+        if self.n_leaves == 0:
+            return np.zeros((0, 3, 3))
+        buf = (C.c_char * (self.n_leaves * 72)).from_address(lib.orc_bvh_leaves(self._h))
+        return np.frombuffer(buf, dtype=np.float64).reshape(-1, 3, 3).copy()
+
+    def leaf_source(self):
+        p = lib.orc_bvh_leaf_source(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.n_leaves,)).copy() if self.n_leaves else np.zeros(0, np.uint32)
+
+    def flat(self):
+        """rtg_bvh view over copies of the oracle's arrays (to hand to the GPU library)."""
+        vn = None
+        p = lib.orc_bvh_vertex_normals(self._h)
+        if p:
+            buf = (C.c_char * (self.n_leaves * 72)).from_address(p)
+            vn = np.frombuffer(buf, dtype=np.float64).copy()
+        return rtg.flat_bvh(self.nodes(), self.leaves(), self.root, vn)
+
+    def raycast(self, ray, counters=False):
+        hit = np.zeros(1, dtype=rtg.HIT_DTYPE)
+        ctr = np.zeros(1, dtype=rtg.COUNTER_DTYPE)
+        lib.orc_bvh_raycast(self._h, d(ray), hit.ctypes.data, ctr.ctypes.data)
+        return (hit[0], ctr[0]) if counters else hit[0]
+
+    def raycast_brute(self, ray):
+        hit = np.zeros(1, dtype=rtg.HIT_DTYPE)
+        lib.orc_bvh_raycast_brute(self._h, d(ray), hit.ctypes.data)
+        return hit[0]
+
+    def close(self):
+        if self._h:
+            lib.orc_bvh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class OracleScene:
+    """objects: rtg.Object list whose `mesh` fields hold OracleBvh handles."""
+    _h = None
+
+    def __init__(self, objects):
+        self._objects = list(objects)
+        arr = (rtg.Object * max(1, len(objects)))()
+        for i, o in enumerate(objects):
+            C.memmove(C.byref(arr[i]), C.byref(o), C.sizeof(rtg.Object))
+        desc = rtg.SceneDesc(arr, len(objects))
+        self._h = lib.orc_scene_create(C.byref(desc))
+
+    def render_primary(self, view, width, height, tile=None, points=False, counters=False, threads=THREADS):
+        x0, y0, w, h = tile if tile is not None else (0, 0, width, height)
+        n = w * h
+        hits = np.empty(n, dtype=rtg.HIT_DTYPE)
+        pts = np.empty(n, dtype=rtg.POINT_DTYPE) if points else None
+        ctr = np.empty(n, dtype=rtg.COUNTER_DTYPE) if counters else None
+        lib.orc_render_primary(self._h, C.byref(view), width, height, rtg.Rect(x0, y0, w, h), hits.ctypes.data,
+                               None if pts is None else pts.ctypes.data, None if ctr is None else ctr.ctypes.data, threads)
+        return hits, pts, ctr
+
+    def trace(self, rays6, points=False, counters=False, threads=THREADS):
+        rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
+        n = rays6.shape[0]
+        hits = np.empty(n, dtype=rtg.HIT_DTYPE)
+        pts = np.empty(n, dtype=rtg.POINT_DTYPE) if points else None
+        ctr = np.empty(n, dtype=rtg.COUNTER_DTYPE) if counters else None
+        lib.orc_trace(self._h, rays6.ctypes.data, n, hits.ctypes.data, None if pts is None else pts.ctypes.data,
+                      None if ctr is None else ctr.ctypes.data, threads)
+        return hits, pts, ctr
+
+    def shade_direct(self, lights, points, rgba8=False, threads=THREADS):
+        lights = np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
+        points = np.ascontiguousarray(points, dtype=rtg.POINT_DTYPE)
+        n = points.shape[0]
+        rgb = np.empty((n, 3), dtype=np.float64)
+        c8 = np.empty((n, 4), dtype=np.uint8) if rgba8 else None
+        lib.orc_shade_direct(self._h, lights.ctypes.data, lights.shape[0], points.ctypes.data, n, rgb.ctypes.data,
+                             None if c8 is None else c8.ctypes.data, threads)
+        return rgb, c8
+
+    def render_frame(self, view, lights, width, height, tile=None, max_depth=4, rgba8=True, hits=True, threads=THREADS):
+        lights = np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
+        x0, y0, w, h = tile if tile is not None else (0, 0, width, height)
+        n = w * h
+        rgb = np.empty((n, 3), dtype=np.float64)
+        c8 = np.empty((n, 4), dtype=np.uint8) if rgba8 else None
+        hh = np.empty(n, dtype=rtg.HIT_DTYPE) if hits else None
+        lib.orc_render_frame(self._h, C.byref(view), lights.ctypes.data, lights.shape[0], width, height,
+                             rtg.Rect(x0, y0, w, h), max_depth, rgb.ctypes.data, None if c8 is None else c8.ctypes.data,
+                             None if hh is None else hh.ctypes.data, threads)
+        return rgb, c8, hh
+
+    def close(self):
+        if self._h:
+            lib.orc_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def oracle_object(obj, oracle_bvh=None):
+    """Copy of an rtg.Object whose mesh handle points at an OracleBvh."""
+    c = rtg.copy_object(obj)
+    c.mesh = oracle_bvh.handle if oracle_bvh is not None else None
+    c._keep = oracle_bvh
+    return c

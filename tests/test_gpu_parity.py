@@ -1,0 +1,268 @@
+"""GPU: the HIP path through the C ABI against the CPU oracle on the same inputs.
+
+Bar: hit object / leaf ids and hit times bit-exact; every other field of the RaycastPoint bit-exact as well
+(the kernels use the reference's operation order in IEEE binary64 with contraction off); 8-bit PQ colour within
+1 LSB (device pow differs from the host libm in the last bits).
+"""
+import numpy as np
+import pytest
+
+import orc
+import scenes
+from raytracer_amd import rtg
+
+pytestmark = pytest.mark.gpu
+
+TRAVERSALS = [0, 1]   # short stack, threaded
+
+
+def _assert_hits_equal(g, c):
+    bad = scenes.hit_mismatches(g, c)
+    assert bad.size == 0, f"{bad.size} mismatching rays, first {bad[:5]}: gpu {g[bad[:5]]} cpu {c[bad[:5]]}"
+
+
+def _assert_points_equal(g, c):
+    for name in rtg.POINT_DTYPE.names:
+        a, b = g[name], c[name]
+        if a.dtype.kind == "f":
+            a, b = a.view(np.uint64), b.view(np.uint64)
+        bad = np.flatnonzero((a != b).reshape(a.shape[0], -1).any(axis=1))
+        assert bad.size == 0, f"field {name}: {bad.size} mismatches, first at {bad[:5]}: gpu {g[name][bad[:3]]} cpu {c[name][bad[:3]]}"
+
+
+@pytest.mark.parametrize("size", [(64, 64), (300, 300), (1024, 1024), (37, 19)])
+def test_default_scene_primary_hits(gpu_ctx, size):
+    """Config 1: sphere + checker plane (src/lib.rs:68-108), primary rays."""
+    objs, lights, view = scenes.default_objects(0)
+    pair = scenes.Pair(gpu_ctx, objs, {})
+    w, h = size
+    g_hits, g_pts, _ = pair.gpu.render_primary(view, w, h, points=True)
+    c_hits, c_pts, _ = pair.cpu.render_primary(view, w, h, points=True)
+    _assert_hits_equal(g_hits, c_hits)
+    _assert_points_equal(g_pts, c_pts)
+    objs_hit = set(np.unique(g_hits["object"]).tolist())
+    assert objs_hit == {0, 1, rtg.RTG_NONE}
+    assert set(np.unique(g_pts["material_slot"][g_hits["object"] == 1]).tolist()) == {2, 3}   # both checker colours
+
+
+def test_tiles_reassemble_to_the_full_frame(gpu_ctx):
+    objs, lights, view = scenes.default_objects(0)
+    pair = scenes.Pair(gpu_ctx, objs, {})
+    w, h = 200, 120
+    full, _, _ = pair.gpu.render_primary(view, w, h)
+    full = full.reshape(h, w)
+    for tile in [(0, 0, 100, 60), (100, 0, 100, 60), (0, 60, 200, 60), (33, 17, 71, 29)]:
+        part, _, _ = pair.gpu.render_primary(view, w, h, tile=tile)
+        x0, y0, tw, th = tile
+        assert scenes.same_hits(part.reshape(th, tw), full[y0:y0 + th, x0:x0 + tw])
+
+
+@pytest.mark.parametrize("traversal", TRAVERSALS)
+@pytest.mark.parametrize("with_normals", [False, True])
+def test_mesh_scene_primary(gpu_ctx, traversal, with_normals):
+    """Sphere + plane + an instanced (scaled) terrain mesh of 20 000 triangles."""
+    gpu_ctx.set_option("traversal", traversal)
+    tris, xform = scenes.terrain(100, 100, seed=7)
+    vn = scenes.vertex_normals_for(tris) if with_normals else None
+    bvh = rtg.HostBvh(tris, vertex_normals=vn)
+    objs, lights, view = scenes.mesh_scene_objects(xform)
+    pair = scenes.Pair(gpu_ctx, objs, {2: bvh})
+    w, h = 320, 200
+    g_hits, g_pts, g_ctr = pair.gpu.render_primary(view, w, h, points=True, counters=True)
+    c_hits, c_pts, c_ctr = pair.cpu.render_primary(view, w, h, points=True, counters=True)
+    _assert_hits_equal(g_hits, c_hits)
+    _assert_points_equal(g_pts, c_pts)
+    assert np.array_equal(g_ctr["nodes_visited"], c_ctr["nodes_visited"])
+    assert np.array_equal(g_ctr["tris_tested"], c_ctr["tris_tested"])
+    assert (g_hits["object"] == 2).mean() > 0.3
+    gpu_ctx.set_option("traversal", 0)
+
+
+@pytest.mark.parametrize("traversal", TRAVERSALS)
+def test_incoherent_batch_rays(gpu_ctx, traversal):
+    """bench_mesh ray distribution (src/tree/benchmark.rs:15-27) against a bare mesh object."""
+    gpu_ctx.set_option("traversal", traversal)
+    tris, xform = scenes.terrain(64, 64, seed=11, local_scale=1.0)
+    bvh = rtg.HostBvh(tris)
+    objs, _, _ = scenes.mesh_scene_objects(rtg.transform(), with_default=False)
+    pair = scenes.Pair(gpu_ctx, objs, {0: bvh})
+    rays = rtg.bench_mesh_rays(bvh.bounds(), 50000, seed=10212233)
+    g_hits, g_pts, g_ctr = pair.gpu.trace(rays, points=True, counters=True)
+    c_hits, c_pts, c_ctr = pair.cpu.trace(rays, points=True, counters=True)
+    _assert_hits_equal(g_hits, c_hits)
+    _assert_points_equal(g_pts, c_pts)
+    assert np.array_equal(g_ctr, c_ctr)
+    assert 0.05 < (g_hits["leaf"] != rtg.RTG_NONE).mean() < 0.95
+    # sorting the batch only permutes the answers
+    perm, sorted_rays = rtg.sort_rays(bvh.bounds(), rays)
+    s_hits, _, _ = pair.gpu.trace(sorted_rays)
+    assert scenes.same_hits(s_hits, g_hits[perm])
+    gpu_ctx.set_option("traversal", 0)
+
+
+@pytest.mark.parametrize("traversal", TRAVERSALS)
+def test_quirks_nan_inf_ties_and_degenerates(gpu_ctx, traversal):
+    """Axis-parallel rays, zero-thickness boxes, degenerate (NaN-time) and coincident triangles."""
+    gpu_ctx.set_option("traversal", traversal)
+    rng = np.random.default_rng(5)
+    base = rng.uniform(-1, 1, size=(200, 1, 3)) + rng.uniform(-0.3, 0.3, size=(200, 3, 3))
+    flat = base[:20].copy()
+    flat[:, :, 2] = flat[:, :1, 2]                      # axis-aligned flat: invisible through the BVH
+    degenerate = base[20:30].copy()
+    degenerate[:, 2] = degenerate[:, 1]                 # zero-area: NaN hit time
+    dup = base[30:40].copy()                            # coincident copies: lowest leaf index wins
+    tris = np.concatenate([base, flat, degenerate, dup])
+    bvh = rtg.HostBvh(tris)
+    objs, _, _ = scenes.mesh_scene_objects(rtg.transform(), with_default=False)
+    pair = scenes.Pair(gpu_ctx, objs, {0: bvh})
+    n = 20000
+    o = rng.uniform(-1.5, 1.5, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    axis = rng.integers(0, 3, size=n)
+    kind = rng.integers(0, 4, size=n)
+    for k in range(3):                                  # a quarter of the rays are exactly axis-parallel
+        sel = (kind == 0) & (axis == k)
+        d[sel] = 0.0
+        d[sel, k] = rng.choice([-1.0, 1.0], size=sel.sum())
+    sel = kind == 1                                     # another quarter has one zero direction component
+    d[sel, axis[sel]] = 0.0
+    rays = np.concatenate([o, d], axis=1)
+    g_hits, g_pts, _ = pair.gpu.trace(rays, points=True)
+    c_hits, c_pts, _ = pair.cpu.trace(rays, points=True)
+    _assert_hits_equal(g_hits, c_hits)
+    _assert_points_equal(g_pts, c_pts)
+    assert np.isnan(g_hits["t"]).any(), "the degenerate triangles should produce NaN-time hits"
+    gpu_ctx.set_option("traversal", 0)
+
+
+def test_deep_tree_uses_every_stack_tier(gpu_ctx):
+    """A skewed mesh whose tree is deeper than the 4 register + 28 LDS levels, so the global overflow slab is used."""
+    rng = np.random.default_rng(8)
+    n = 3000
+    c = np.zeros((n, 1, 3))
+    c[:, 0, 0] = np.exp(rng.uniform(0, 40, size=n))     # 1 % clamp on every split -> depth in the hundreds
+    c[:, 0, 1:] = rng.uniform(-1, 1, size=(n, 2))
+    tris = c + rng.uniform(-0.5, 0.5, size=(n, 3, 3))
+    bvh = rtg.HostBvh(tris)
+    assert bvh.depth > 40
+    objs, _, _ = scenes.mesh_scene_objects(rtg.transform(), with_default=False)
+    pair = scenes.Pair(gpu_ctx, objs, {0: bvh})
+    m = 4096
+    o = np.stack([np.exp(rng.uniform(0, 40, size=m)), rng.uniform(-1, 1, size=m), np.full(m, 5.0)], axis=1)
+    d = np.tile([0.0, 0.0, -1.0], (m, 1)) + rng.normal(scale=0.05, size=(m, 3))
+    rays = np.concatenate([o, d], axis=1)
+    c_hits, _, c_ctr = pair.cpu.trace(rays, counters=True)
+    for traversal in TRAVERSALS:
+        gpu_ctx.set_option("traversal", traversal)
+        g_hits, _, g_ctr = pair.gpu.trace(rays, counters=True)
+        _assert_hits_equal(g_hits, c_hits)
+        assert np.array_equal(g_ctr, c_ctr)
+    gpu_ctx.set_option("traversal", 0)
+
+
+def test_empty_inputs(gpu_ctx):
+    objs, lights, view = scenes.default_objects(0)
+    pair = scenes.Pair(gpu_ctx, objs, {})
+    hits, _, _ = pair.gpu.trace(np.zeros((0, 6)))
+    assert hits.shape == (0,)
+    hits, _, _ = pair.gpu.render_primary(view, 16, 16, tile=(3, 3, 0, 5))
+    assert hits.shape == (0,)
+    empty = scenes.Pair(gpu_ctx, [], {})                 # a scene with no objects: every ray misses
+    hits, pts, _ = empty.gpu.render_primary(view, 8, 8, points=True)
+    assert (hits["object"] == rtg.RTG_NONE).all() and np.isinf(hits["t"]).all() and (pts["manifold_len"] == 0).all()
+    bvh = rtg.HostBvh(np.zeros((0, 3, 3)))               # an empty mesh
+    mobjs, _, _ = scenes.mesh_scene_objects(rtg.transform(), with_default=False)
+    pm = scenes.Pair(gpu_ctx, mobjs, {0: bvh})
+    g, _, _ = pm.gpu.render_primary(view, 8, 8)
+    c, _, _ = pm.cpu.render_primary(view, 8, 8)
+    _assert_hits_equal(g, c)
+
+
+def test_invalid_requests_are_reported(gpu_ctx):
+    objs, lights, view = scenes.default_objects(0)
+    pair = scenes.Pair(gpu_ctx, objs, {})
+    with pytest.raises(rtg.RtgError) as e:
+        pair.gpu.render_primary(view, 16, 16, tile=(8, 8, 16, 16))
+    assert e.value.code == -1 and "outside" in str(e.value)
+    nodes = np.zeros(2, dtype=rtg.NODE_DTYPE)
+    nodes[1]["child_begin"], nodes[1]["child_end"] = 0, 2     # node 1 lists itself as a child
+    with pytest.raises(rtg.RtgError) as e:
+        gpu_ctx.mesh(rtg.flat_bvh(nodes, np.zeros((0, 3, 3)), 1))
+    assert "reachable twice" in str(e.value)
+    nodes[1]["child_end"] = 5
+    with pytest.raises(rtg.RtgError):
+        gpu_ctx.mesh(rtg.flat_bvh(nodes, np.zeros((0, 3, 3)), 1))
+
+
+@pytest.mark.parametrize("time", [0, 13])
+def test_direct_shading_default_scene(gpu_ctx, time):
+    """compute_direct_irrad x diffuse (src/render/renderer.rs:184-205,270-277)."""
+    objs, lights, view = scenes.default_objects(time)
+    pair = scenes.Pair(gpu_ctx, objs, {})
+    w, h = 256, 256
+    _, g_pts, _ = pair.gpu.render_primary(view, w, h, points=True)
+    g_rgb, g_c8 = pair.gpu.shade_direct(lights, g_pts, rgba8=True)
+    c_rgb, c_c8 = pair.cpu.shade_direct(lights, g_pts, rgba8=True)
+    assert np.array_equal(g_rgb.view(np.uint64), c_rgb.view(np.uint64))       # linear radiance bit-exact
+    assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1            # 8-bit PQ colour within 1 LSB
+    assert g_rgb.max() > 1.0 and (g_rgb[:, 0] == 0).all()                      # blue + green lights only
+
+
+@pytest.mark.parametrize("max_depth", [1, 4])
+def test_fused_frame_default_scene(gpu_ctx, max_depth):
+    """raytrace_pixel with the specular path tree (src/render/renderer.rs:266-378), photon term empty."""
+    objs, lights, view = scenes.default_objects(5)
+    pair = scenes.Pair(gpu_ctx, objs, {})
+    w, h = 300, 300
+    g_rgb, g_c8, g_hits = pair.gpu.render_frame(view, lights, w, h, max_depth=max_depth)
+    c_rgb, c_c8, c_hits = pair.cpu.render_frame(view, lights, w, h, max_depth=max_depth)
+    _assert_hits_equal(g_hits, c_hits)
+    assert np.array_equal(g_rgb.view(np.uint64), c_rgb.view(np.uint64))
+    assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1
+    sphere = g_hits["object"] == 0
+    if max_depth == 1:
+        assert (g_rgb[sphere] == 0).all()                   # diffuse 0 and no specular paths: a black disc
+    else:
+        assert (g_rgb[sphere].sum(axis=1) > 0).mean() > 0.5  # the glass ball shows the floor through it
+
+
+def test_fused_frame_mesh_scene_and_cpp_renderer(gpu_ctx):
+    tris, xform = scenes.terrain(60, 60, seed=3)
+    bvh = rtg.HostBvh(tris)
+    objs, lights, view = scenes.mesh_scene_objects(xform, time=40)
+    pair = scenes.Pair(gpu_ctx, objs, {2: bvh})
+    w, h = 160, 96
+    g_rgb, g_c8, g_hits = pair.gpu.render_frame(view, lights, w, h, max_depth=4)
+    c_rgb, c_c8, c_hits = pair.cpu.render_frame(view, lights, w, h, max_depth=4)
+    _assert_hits_equal(g_hits, c_hits)
+    assert np.array_equal(g_rgb.view(np.uint64), c_rgb.view(np.uint64))
+    assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1
+    # the C++ Renderer (host mirror of Renderer::new/render) drives the same path
+    r_rgb, r_hits = rtg.render_scene_builder(gpu_ctx, 5, 120, 80, max_depth=4)
+    objs, lights, view = scenes.default_objects(5)
+    p2 = scenes.Pair(gpu_ctx, objs, {})
+    c_rgb, _, c_hits = p2.cpu.render_frame(view, lights, 120, 80, max_depth=4)
+    _assert_hits_equal(r_hits, c_hits)
+    assert np.array_equal(r_rgb.view(np.uint64), c_rgb.view(np.uint64))
+    hdr = rtg.to_hdr(r_rgb, 120, 80)
+    assert hdr.startswith(b"#?RADIANCE\n") and len(hdr) > 120 * 80 * 4
+
+
+def test_device_f64_div_and_sqrt_are_correctly_rounded(gpu_ctx):
+    """The parity argument rests on IEEE-exact device / and sqrt: sweep them through the ray normalisation."""
+    import math
+    rng = np.random.default_rng(1)
+    n = 200000
+    o = rng.uniform(-10, 10, size=(n, 3))
+    d = rng.normal(size=(n, 3)) * np.exp(rng.uniform(-20, 20, size=(n, 1)))
+    rays = np.concatenate([o, d], axis=1)
+    # one huge sphere around everything: t comes from sqrt and three divisions of unnormalised data
+    objs = [rtg.sphere_object((0.5, -0.25, 0.125), 100.0, rtg.material((1, 1, 1)))]
+    pair = scenes.Pair(gpu_ctx, objs, {})
+    g_hits, g_pts, _ = pair.gpu.trace(rays, points=True)
+    c_hits, c_pts, _ = pair.cpu.trace(rays, points=True)
+    _assert_hits_equal(g_hits, c_hits)
+    _assert_points_equal(g_pts, c_pts)
+    assert (g_hits["object"] == 0).all()
+    del math

@@ -1,0 +1,127 @@
+"""CPU: the host library's index-based BvhForest::subdivide + Bvh::new against the oracle's literal restatement,
+plus the flatten invariants and the traversal-vs-brute-force property on the oracle."""
+import numpy as np
+import pytest
+
+import orc
+from raytracer_amd import rtg
+
+
+def _same_tree(h, o):
+    assert h.n_nodes == o.n_nodes and h.n_leaves == o.n_leaves and h.root == o.root
+    assert h.nodes().tobytes() == o.nodes().tobytes()
+    assert h.leaves().tobytes() == o.leaves().tobytes()
+    assert np.array_equal(h.leaf_source(), o.leaf_source())
+    assert h.depth == o.depth
+
+
+def _random_tris(n, seed, spread=1.0):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-1, 1, size=(n, 1, 3)) * spread
+    return c + rng.uniform(-0.05, 0.05, size=(n, 3, 3))
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (3, 3), (17, 4), (257, 5), (5000, 6)])
+def test_builder_matches_oracle_random(n, seed):
+    tris = _random_tris(n, seed)
+    _same_tree(rtg.HostBvh(tris, threads=1), orc.OracleBvh(tris))
+    _same_tree(rtg.HostBvh(tris, threads=4), orc.OracleBvh(tris))
+
+
+def test_builder_matches_oracle_grid_with_ties():
+    # a regular grid has many equal centres on the split coordinate: exercises the
+    # binary-search tie rule and the stability of the sort
+    tris = rtg.heightfield(32, 16, seed=3, scale=1.0)
+    flat = tris.copy()
+    flat[:, :, 1] = np.round(flat[:, :, 1] * 4) / 4      # more exact ties
+    for t in (tris, flat):
+        _same_tree(rtg.HostBvh(t, threads=3), orc.OracleBvh(t))
+
+
+def test_builder_duplicates_and_clamp():
+    one = _random_tris(1, 9)
+    tris = np.repeat(one, 300, axis=0)                    # all centres equal: split clamps to 1 %
+    h, o = rtg.HostBvh(tris), orc.OracleBvh(tris)
+    _same_tree(h, o)
+    skew = _random_tris(400, 10)
+    skew[:, :, 0] = np.exp(skew[:, :, 0] * 12)            # heavy tail along x
+    _same_tree(rtg.HostBvh(skew), orc.OracleBvh(skew))
+
+
+def test_builder_large_parallel():
+    tris = rtg.heightfield(200, 100, seed=5, scale=100.0)  # 40 000 triangles, threaded sort + subtrees
+    _same_tree(rtg.HostBvh(tris, threads=8), orc.OracleBvh(tris))
+
+
+def test_empty_and_single():
+    h = rtg.HostBvh(np.zeros((0, 3, 3)))
+    o = orc.OracleBvh(np.zeros((0, 3, 3)))
+    _same_tree(h, o)
+    n = h.nodes()
+    assert h.n_nodes == 1 and h.n_leaves == 0 and np.all(n[0]["lo"] == np.inf) and np.all(n[0]["hi"] == -np.inf)
+    assert o.raycast([0, 0, 1, 0, 0, -1])["leaf"] == rtg.RTG_NONE
+    h1 = rtg.HostBvh(_random_tris(1, 3))
+    assert h1.n_nodes == 1 and h1.n_leaves == 1 and h1.root == 0
+
+
+def test_flatten_invariants():
+    tris = _random_tris(500, 11)
+    h = rtg.HostBvh(tris)
+    nodes = h.nodes()
+    assert h.n_nodes == 2 * 500 - 1 and h.root == h.n_nodes - 1
+    # leaves are numbered in traversal (DFS pre-) order; children are contiguous and come after their descendants
+    order = []
+
+    def walk(i):
+        n = nodes[i]
+        order.extend(range(n["leaf_begin"], n["leaf_end"]))
+        assert n["child_end"] <= i or n["child_begin"] == n["child_end"]
+        for c in range(n["child_begin"], n["child_end"]):
+            walk(c)
+    walk(h.root)
+    assert order == list(range(500))
+    assert np.array_equal(h.leaves(), tris[h.leaf_source()])
+    # the root box is the union of all triangle boxes
+    assert np.array_equal(h.bounds(), np.concatenate([tris.min(axis=(0, 1)), tris.max(axis=(0, 1))]))
+
+
+def test_traversal_equals_brute_force_on_random_meshes():
+    rng = np.random.default_rng(12)
+    tris = _random_tris(800, 13)
+    tris = tris.mean(axis=1, keepdims=True) + (tris - tris.mean(axis=1, keepdims=True)) * 4.0   # bigger faces
+    o = orc.OracleBvh(tris)
+    lo, hi = tris.min(axis=(0, 1)), tris.max(axis=(0, 1))
+    rays = rtg.bench_mesh_rays(np.concatenate([lo, hi]), 3000, seed=99)
+    n_hit = 0
+    for r in rays:
+        a, b = o.raycast(r), o.raycast_brute(r)
+        assert a["leaf"] == b["leaf"] and (a["t"] == b["t"] or (np.isnan(a["t"]) and np.isnan(b["t"])))
+        n_hit += a["leaf"] != rtg.RTG_NONE
+    assert n_hit > 200
+    del rng
+
+
+def test_tie_rule_lowest_leaf_index_wins():
+    t = np.array([[[0, 0, 0], [1, 0, 0.125], [0, 1, 0.25]]], dtype=np.float64)   # tilted: its box has thickness
+    tris = np.concatenate([t, t, t + [0, 0, -1.0]])       # two coincident triangles and one behind
+    o = orc.OracleBvh(tris)
+    hit = o.raycast([.25, .25, 1, 0, 0, -1])
+    src = o.leaf_source()
+    coincident = sorted(i for i in range(3) if src[i] in (0, 1))
+    assert hit["t"] == 1.0 - (0.25 * 0.125 + 0.25 * 0.25) and hit["leaf"] == coincident[0]
+
+
+def test_flat_axis_aligned_triangle_is_never_hit_through_the_bvh():
+    # quirk: the leaf's box has zero thickness along z, so the slab test returns None (strict <)
+    tris = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], dtype=np.float64)
+    o = orc.OracleBvh(tris)
+    assert o.raycast([.25, .25, 1, 0, 0, -1])["leaf"] == rtg.RTG_NONE
+    assert o.raycast_brute([.25, .25, 1, 0, 0, -1])["leaf"] == 0
+
+
+def test_counters_count_every_visited_node():
+    tris = _random_tris(64, 21)
+    o = orc.OracleBvh(tris)
+    # a ray that misses the root box visits exactly one node and no triangle
+    hit, ctr = o.raycast([50, 50, 50, 0, 0, 1], counters=True)
+    assert hit["leaf"] == rtg.RTG_NONE and ctr["nodes_visited"] == 1 and ctr["tris_tested"] == 0
