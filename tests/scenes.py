@@ -71,12 +71,19 @@ def mesh_scene_objects(xform, with_default=True, time=0, diffuse=(0.8, 0.7, 0.6)
     return [mesh], lights, view
 
 
-def same_hits(a, b):
-    """Bit-exact comparison of two HIT_DTYPE arrays (NaN times compare by bit pattern)."""
-    return (np.array_equal(a["object"], b["object"]) and np.array_equal(a["leaf"], b["leaf"])
-            and np.array_equal(a["t"].view(np.uint64), b["t"].view(np.uint64)))
+def float_bits_differ(a, b):
+    """Elementwise: True where two float64 arrays differ in any bit, except that any NaN equals any NaN
+    (NaN sign and payload are hardware conventions: x86 produces a negative default NaN, gfx950 a positive one)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return (a.view(np.uint64) != b.view(np.uint64)) & ~(np.isnan(a) & np.isnan(b))
 
 
 def hit_mismatches(a, b):
-    bad = (a["object"] != b["object"]) | (a["leaf"] != b["leaf"]) | (a["t"].view(np.uint64) != b["t"].view(np.uint64))
+    bad = (a["object"] != b["object"]) | (a["leaf"] != b["leaf"]) | float_bits_differ(a["t"], b["t"])
     return np.flatnonzero(bad)
+
+
+def same_hits(a, b):
+    """Bit-exact comparison of two HIT_DTYPE arrays."""
+    return hit_mismatches(a.reshape(-1), b.reshape(-1)).size == 0

@@ -24,9 +24,8 @@ def _assert_hits_equal(g, c):
 def _assert_points_equal(g, c):
     for name in rtg.POINT_DTYPE.names:
         a, b = g[name], c[name]
-        if a.dtype.kind == "f":
-            a, b = a.view(np.uint64), b.view(np.uint64)
-        bad = np.flatnonzero((a != b).reshape(a.shape[0], -1).any(axis=1))
+        diff = scenes.float_bits_differ(a, b) if a.dtype.kind == "f" else (a != b)
+        bad = np.flatnonzero(diff.reshape(a.shape[0], -1).any(axis=1))
         assert bad.size == 0, f"field {name}: {bad.size} mismatches, first at {bad[:5]}: gpu {g[name][bad[:3]]} cpu {c[name][bad[:3]]}"
 
 
@@ -204,7 +203,7 @@ def test_direct_shading_default_scene(gpu_ctx, time):
     _, g_pts, _ = pair.gpu.render_primary(view, w, h, points=True)
     g_rgb, g_c8 = pair.gpu.shade_direct(lights, g_pts, rgba8=True)
     c_rgb, c_c8 = pair.cpu.shade_direct(lights, g_pts, rgba8=True)
-    assert np.array_equal(g_rgb.view(np.uint64), c_rgb.view(np.uint64))       # linear radiance bit-exact
+    assert not scenes.float_bits_differ(g_rgb, c_rgb).any()                     # linear radiance bit-exact
     assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1            # 8-bit PQ colour within 1 LSB
     assert g_rgb.max() > 1.0 and (g_rgb[:, 0] == 0).all()                      # blue + green lights only
 
@@ -218,7 +217,7 @@ def test_fused_frame_default_scene(gpu_ctx, max_depth):
     g_rgb, g_c8, g_hits = pair.gpu.render_frame(view, lights, w, h, max_depth=max_depth)
     c_rgb, c_c8, c_hits = pair.cpu.render_frame(view, lights, w, h, max_depth=max_depth)
     _assert_hits_equal(g_hits, c_hits)
-    assert np.array_equal(g_rgb.view(np.uint64), c_rgb.view(np.uint64))
+    assert not scenes.float_bits_differ(g_rgb, c_rgb).any()
     assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1
     sphere = g_hits["object"] == 0
     if max_depth == 1:
@@ -236,7 +235,7 @@ def test_fused_frame_mesh_scene_and_cpp_renderer(gpu_ctx):
     g_rgb, g_c8, g_hits = pair.gpu.render_frame(view, lights, w, h, max_depth=4)
     c_rgb, c_c8, c_hits = pair.cpu.render_frame(view, lights, w, h, max_depth=4)
     _assert_hits_equal(g_hits, c_hits)
-    assert np.array_equal(g_rgb.view(np.uint64), c_rgb.view(np.uint64))
+    assert not scenes.float_bits_differ(g_rgb, c_rgb).any()
     assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1
     # the C++ Renderer (host mirror of Renderer::new/render) drives the same path
     r_rgb, r_hits = rtg.render_scene_builder(gpu_ctx, 5, 120, 80, max_depth=4)
@@ -244,7 +243,7 @@ def test_fused_frame_mesh_scene_and_cpp_renderer(gpu_ctx):
     p2 = scenes.Pair(gpu_ctx, objs, {})
     c_rgb, _, c_hits = p2.cpu.render_frame(view, lights, 120, 80, max_depth=4)
     _assert_hits_equal(r_hits, c_hits)
-    assert np.array_equal(r_rgb.view(np.uint64), c_rgb.view(np.uint64))
+    assert not scenes.float_bits_differ(r_rgb, c_rgb).any()
     hdr = rtg.to_hdr(r_rgb, 120, 80)
     assert hdr.startswith(b"#?RADIANCE\n") and len(hdr) > 120 * 80 * 4
 
