@@ -40,7 +40,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--traversal", type=int, default=-1, help="0 short stack, 1 threaded, -1 library default")
+    ap.add_argument("--traversal", type=int, default=-1, help="0 short stack, 1 threaded, 2 phased threaded, -1 library default")
+    ap.add_argument("--opt", action="append", default=[], help="ctx option key=value (e.g. tri_min=16)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--grid", type=str, default=None, help="NXxNY quads (default 1000x500)")
     args = ap.parse_args()
@@ -70,6 +71,9 @@ def main():
     ctx = rtg.Context(local_rank)
     if args.traversal >= 0:
         ctx.set_option("traversal", args.traversal)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     stream = torch.cuda.Stream(dev)               # a real (non-null) stream: kernels, events and RCCL share it
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
@@ -148,7 +152,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"config 2: {2 * nx * ny}-triangle terrain BVH ({bvh.n_nodes} nodes, depth {bvh.depth}), "
                                    f"{WIDTH}x{HEIGHT} primary rays per step per GPU, closest-hit ids",
-                       "traversal": "library default" if args.traversal < 0 else ("short-stack" if args.traversal == 0 else "threaded"),
+                       "traversal": "library default" if args.traversal < 0 else ["short-stack", "threaded", "phased-threaded"][args.traversal],
                        "parallelism": f"frames sharded over {world} GPU(s), BVH replicated" + (", RCCL gather to rank 0" if world > 1 else ""),
                        "host_bvh_build_s": round(build_s, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

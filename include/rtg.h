@@ -174,9 +174,18 @@ const char *rtg_last_error(rtg_ctx *ctx);
 int rtg_ctx_set_stream(rtg_ctx *ctx, void *hip_stream);
 void *rtg_ctx_get_stream(rtg_ctx *ctx);
 int rtg_ctx_synchronize(rtg_ctx *ctx);
-/* Options: "traversal" 0 = short-stack (VGPR window + LDS spill),
- *                      1 = threaded pre-order (skip links). */
+/* Options (no reference counterpart; tuning and A/B switches):
+ *   "traversal" 0 = one ray per lane, short stack (VGPR window + LDS spill + global overflow)
+ *               1 = one ray per lane, threaded pre-order tree (skip links, no stack)
+ *               2 = persistent phase-scheduled waves over the threaded tree
+ *   "tri_min" / "obj_min" / "idle_min"  scheduling thresholds of traversal 2 (lanes)
+ *   "max_blocks"                        persistent grid size of traversal 2
+ *   "stats" 2 = tally steps per phase in traversal 2 (diagnostics), 1 = off */
 int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value);
+/* Diagnostics for traversal 2 after a launch with "stats" on: loop iterations,
+ * node steps, node lanes, tri steps, tri lanes, obj steps, obj lanes, refills,
+ * waves (no reference counterpart). */
+int rtg_ctx_debug_stats(rtg_ctx *ctx, uint32_t out[16]);
 
 /* Restates `Transform::from(Mat4)` (src/geo/transform.rs:51-58) with the
  * inverse formulas of src/math/mat.rs:80-87,100-154 for callers that only hold

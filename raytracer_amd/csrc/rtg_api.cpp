@@ -7,6 +7,7 @@
 // point that needs one fails with RTG_E_NODEVICE / RTG_E_HIP.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -32,7 +33,8 @@ struct rtg_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    int traversal = 0;
+    int traversal = 2;
+    PhasedTuning tune;
     std::string err;
     std::map<std::string, DeviceBuffer> scratch;
 };
@@ -127,6 +129,7 @@ int out_prepare(rtg_ctx *ctx, const char *name, void *user, size_t bytes, Out &o
         return RTG_OK;
     }
     if (is_device_pointer(user)) {
+        if ((uintptr_t)user % 16 != 0) return fail(ctx, RTG_E_INVALID, "device output '%s' must be 16-byte aligned", name);
         o.dev = user;
         return RTG_OK;
     }
@@ -287,7 +290,7 @@ int check_scene_call(rtg_scene *scene) {
 int scene_for_launch(rtg_scene *scene, uint64_t threads, DevScene &out) {
     rtg_ctx *ctx = scene->ctx;
     out = scene->dev;
-    out.traversal = (uint32_t)ctx->traversal;
+    out.traversal = ctx->traversal == 0 ? 0u : 1u;
     out.overflow = nullptr;
     out.overflow_levels = 0;
     out.overflow_stride = 1;
@@ -371,11 +374,44 @@ int rtg_ctx_synchronize(rtg_ctx *ctx) {
 int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) {
     if (!ctx || !key) return fail(ctx, RTG_E_INVALID, "null ctx or key");
     if (std::strcmp(key, "traversal") == 0) {
-        if (value != 0 && value != 1) return fail(ctx, RTG_E_INVALID, "traversal must be 0 (short stack) or 1 (threaded)");
+        if (value < 0 || value > 2)
+            return fail(ctx, RTG_E_INVALID, "traversal must be 0 (short stack), 1 (threaded) or 2 (phased threaded)");
         ctx->traversal = (int)value;
         return RTG_OK;
     }
+    if (value < 1 || value > (1 << 20)) return fail(ctx, RTG_E_INVALID, "option '%s': value out of range", key);
+    if (std::strcmp(key, "tri_min") == 0) {
+        ctx->tune.tri_min = (uint32_t)(value > 64 ? 64 : value);
+        return RTG_OK;
+    }
+    if (std::strcmp(key, "obj_min") == 0) {
+        ctx->tune.obj_min = (uint32_t)(value > 64 ? 64 : value);
+        return RTG_OK;
+    }
+    if (std::strcmp(key, "idle_min") == 0) {
+        ctx->tune.idle_min = (uint32_t)(value > 64 ? 64 : value);
+        return RTG_OK;
+    }
+    if (std::strcmp(key, "max_blocks") == 0) {
+        ctx->tune.max_blocks = (uint32_t)value;
+        return RTG_OK;
+    }
+    if (std::strcmp(key, "stats") == 0) {
+        ctx->tune.stats = value > 1 ? 1u : 0u;   // 2 = on, 1 = off (0 is rejected above as out of range)
+        return RTG_OK;
+    }
     return fail(ctx, RTG_E_INVALID, "unknown option '%s'", key);
+}
+
+int rtg_ctx_debug_stats(rtg_ctx *ctx, uint32_t out[16]) {
+    if (!ctx || !out) return fail(ctx, RTG_E_INVALID, "null argument");
+    int rc = bind_device(ctx);
+    if (rc != RTG_OK) return rc;
+    auto it = ctx->scratch.find("work_counters");
+    if (it == ctx->scratch.end() || !it->second.ptr) return fail(ctx, RTG_E_INVALID, "no phased launch has run on this context");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, (const uint32_t *)it->second.ptr + 8 * 32, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RTG_OK;
 }
 
 int rtg_transform_from_forward(const double forward[16], rtg_transform *out) {
@@ -438,6 +474,15 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) {
     m->dev.n_nodes = (uint32_t)thr_nodes.size();
     m->dev.root = bvh->root;
     m->dev.depth = depth;
+    // window inside which the reciprocal-based box test is exact (see rtg_phased.hip)
+    uint32_t fast_ok = 1;
+    for (const DevNode &n : thr_nodes)
+        for (int k = 0; k < 3 && fast_ok; k++)
+            for (double c : {n.lo[k], n.hi[k]}) {
+                double a = std::fabs(c);
+                if (!(c == 0.0 || (a >= 0x1p-600 && a <= 0x1p400))) fast_ok = 0;
+            }
+    m->dev.fast_div_ok = fast_ok;
     *out = m;
     return RTG_OK;
 }
@@ -553,8 +598,15 @@ int rtg_render_primary(rtg_scene *scene, const rtg_view *view, uint32_t width, u
     if ((rc = out_prepare(ctx, "out_counters", out_counters, n * sizeof(rtg_ray_counters), oc)) != RTG_OK) return rc;
     DevScene ds;
     if ((rc = scene_for_launch(scene, tiles * kBlock, ds)) != RTG_OK) return rc;
-    HIP_TRY(ctx, launch_render_primary(ctx->stream, ds, *view, width, height, tile, (rtg_hit *)oh.dev,
-                                       (rtg_point *)op.dev, (rtg_ray_counters *)oc.dev));
+    if (ctx->traversal == 2) {
+        void *wc = nullptr;
+        if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
+        HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, (uint32_t *)wc, ctx->tune,
+                                                  (rtg_hit *)oh.dev, (rtg_point *)op.dev, (rtg_ray_counters *)oc.dev));
+    } else {
+        HIP_TRY(ctx, launch_render_primary(ctx->stream, ds, *view, width, height, tile, (rtg_hit *)oh.dev,
+                                           (rtg_point *)op.dev, (rtg_ray_counters *)oc.dev));
+    }
     if ((rc = out_finish(ctx, oh)) != RTG_OK) return rc;
     if ((rc = out_finish(ctx, op)) != RTG_OK) return rc;
     if ((rc = out_finish(ctx, oc)) != RTG_OK) return rc;
@@ -582,8 +634,15 @@ int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *o
     DevScene ds;
     uint64_t threads = (n_rays + kBlock - 1) / kBlock * kBlock;
     if ((rc = scene_for_launch(scene, threads, ds)) != RTG_OK) return rc;
-    HIP_TRY(ctx, launch_trace(ctx->stream, ds, (const double *)d_rays, n_rays, (rtg_hit *)oh.dev, (rtg_point *)op.dev,
-                              (rtg_ray_counters *)oc.dev));
+    if (ctx->traversal == 2) {
+        void *wc = nullptr;
+        if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
+        HIP_TRY(ctx, launch_trace_phased(ctx->stream, ds, (const double *)d_rays, n_rays, (uint32_t *)wc, ctx->tune,
+                                         (rtg_hit *)oh.dev, (rtg_point *)op.dev, (rtg_ray_counters *)oc.dev));
+    } else {
+        HIP_TRY(ctx, launch_trace(ctx->stream, ds, (const double *)d_rays, n_rays, (rtg_hit *)oh.dev,
+                                  (rtg_point *)op.dev, (rtg_ray_counters *)oc.dev));
+    }
     if ((rc = out_finish(ctx, oh)) != RTG_OK) return rc;
     if ((rc = out_finish(ctx, op)) != RTG_OK) return rc;
     if ((rc = out_finish(ctx, oc)) != RTG_OK) return rc;

@@ -46,7 +46,7 @@ struct DevMesh {
     uint32_t n_nodes;
     uint32_t root;
     uint32_t depth;
-    uint32_t pad;
+    uint32_t fast_div_ok;        // every box coordinate is 0 or has 2^-600 <= |c| <= 2^400
 };
 
 struct DevMaterial {

@@ -17,4 +17,20 @@ hipError_t launch_render_frame(hipStream_t stream, const DevScene &s, const rtg_
                                uint32_t n_lights, uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth,
                                double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits);
 
+// Persistent phase-scheduled kernels (rtg_phased.hip).
+struct PhasedTuning {
+    uint32_t tri_min = 8;
+    uint32_t obj_min = 4;
+    uint32_t idle_min = 12;
+    uint32_t max_blocks = 1024;
+    uint32_t stats = 0;          // diagnostics build: tally steps and lanes per phase
+};
+hipError_t launch_render_primary_phased(hipStream_t stream, const DevScene &s, const rtg_view &view, uint32_t width,
+                                        uint32_t height, rtg_rect tile, uint32_t *work_counters,
+                                        const PhasedTuning &tune, rtg_hit *out_hits, rtg_point *out_points,
+                                        rtg_ray_counters *out_counters);
+hipError_t launch_trace_phased(hipStream_t stream, const DevScene &s, const double *rays6, uint64_t n,
+                               uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits,
+                               rtg_point *out_points, rtg_ray_counters *out_counters);
+
 } // namespace rtg

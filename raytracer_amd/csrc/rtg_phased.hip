@@ -1,0 +1,517 @@
+// rtg_phased.hip -- persistent, phase-scheduled closest-hit kernel for gfx950.
+//
+// Why: in the one-ray-per-lane kernels a wave runs until its slowest ray is
+// done (55 % of the lanes active on the 1M-triangle frame) and executes the
+// triangle test in almost every loop iteration for two or three lanes.  Here a
+// lane is a small state machine -- IDLE, OBJ (between objects of the scene),
+// NODE (one box test of the threaded pre-order tree), TRI (one triangle of a
+// leaf range) -- and the wave runs one phase at a time for the lanes that are
+// in it:
+//   * NODE steps run whenever any lane has a node to test;
+//   * TRI steps wait until `tri_min` lanes have a triangle pending (or no lane
+//     can do a node step), so the expensive triangle code runs for many lanes
+//     at once; a lane with a pending triangle does not advance, so every ray
+//     still sees exactly the reference's visit order and best-time pruning
+//     (tree/bvh.rs:118-133);
+//   * finished lanes go IDLE and are refilled with new rays once `idle_min`
+//     lanes are idle, from 64-ray chunks handed out by per-XCD work counters
+//     (blocks b and b+8 share an XCD and its L2, so each XCD first drains its
+//     own contiguous eighth of the frame and only then helps the others).
+//
+// The box test divides by the ray direction six times per node.  The
+// direction is constant per ray, so the quotient is rebuilt from r = 1/d
+// (one IEEE division per ray and axis) with two FMA refinement steps:
+//   q0 = x*r; e0 = fma(-q0,d,x); q1 = fma(e0,r,q0); e1 = fma(-q1,d,x); q = fma(e1,r,q1)
+// q1 is a faithful quotient, the residual e1 is then exact, and with r the
+// correctly rounded reciprocal the last step returns the correctly rounded
+// x/d (Markstein's theorem), i.e. the bits an IEEE division returns, provided
+// nothing over/underflows on the way.  Rays and meshes whose magnitudes could
+// do that (see fast_div_ray_ok / the host's mesh check) take the plain
+// division path; results are identical either way.
+#include "rtg_device.hpp"
+#include "rtg_launch.hpp"
+
+namespace rtg {
+
+enum : uint32_t { PH_IDLE = 0, PH_OBJ = 1, PH_NODE = 2, PH_TRI = 3 };
+
+// ---- ray sources ------------------------------------------------------------------
+struct PrimarySource {
+    rtg_view view;
+    uint32_t width, height;
+    rtg_rect tile;
+    uint32_t tiles_x;     // 8x8 tiles per row of the rectangle
+    // item -> pixel: items are numbered tile by tile, 64 per tile, row-major inside the tile
+    __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
+        uint32_t t = (uint32_t)(item >> 6), l = (uint32_t)item & 63u;
+        uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+        uint32_t px = tx * 8 + (l & 7u), py = ty * 8 + (l >> 3);
+        if (px >= tile.w || py >= tile.h) return false;
+        out_index = (uint64_t)py * tile.w + px;
+        ray = primary_ray(view, tile.x0 + px, tile.y0 + py, width, height);
+        return true;
+    }
+};
+struct BatchSource {
+    const double *rays6;
+    uint64_t n;
+    __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
+        if (item >= n) return false;
+        const double2 *q = reinterpret_cast<const double2 *>(rays6 + item * 6);
+        double2 a = q[0], b = q[1], c = q[2];
+        ray = Ray{mk(a.x, a.y, b.x), mk(b.y, c.x, c.y)};
+        out_index = item;
+        return true;
+    }
+};
+
+// ---- exact division by a per-ray constant ------------------------------------------
+__device__ __forceinline__ double div_by_const(double x, double d, double r) {
+    double q0 = x * r;
+    double e0 = __builtin_fma(-q0, d, x);
+    double q1 = __builtin_fma(e0, r, q0);
+    double e1 = __builtin_fma(-q1, d, x);
+    return __builtin_fma(e1, r, q1);
+}
+// Magnitude windows inside which no intermediate of div_by_const can overflow,
+// underflow or lose an exact residual (box coordinates are checked on the host
+// with the same origin window).
+__device__ __forceinline__ bool in_window(double v, double lo, double hi) {
+    double a = __builtin_fabs(v);
+    return v == 0.0 || (a >= lo && a <= hi);
+}
+__device__ __forceinline__ bool fast_div_ray_ok(const Ray &r) {
+    const double dlo = 0x1p-100, dhi = 0x1p100, olo = 0x1p-600, ohi = 0x1p400;
+    return in_window(r.d.x, dlo, dhi) && in_window(r.d.y, dlo, dhi) && in_window(r.d.z, dlo, dhi) &&
+           in_window(r.o.x, olo, ohi) && in_window(r.o.y, olo, ohi) && in_window(r.o.z, olo, ohi);
+}
+
+// v_min_f64 / v_max_f64 as the hardware defines them (IEEE-754 minNum/maxNum: a quiet
+// NaN operand is ignored).  Written as asm so the compiler does not add a
+// canonicalising v_max_f64 x,x in front of every use.
+__device__ __forceinline__ double hw_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double hw_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Box test for a lane inside the fast-division window.  There every quotient is
+// finite unless the direction component is 0, and then both plane times of the
+// axis come out as quiet NaN (x*inf is inf or NaN, the residual fma is NaN): the
+// reference skips exactly those axes (geo/bounds.rs:85), and min/max ignore the
+// NaNs, so no per-axis test is needed.  The per-axis `min < max` checks of
+// Interval::intersect collapse into the final one because the lower bound only
+// grows and the upper bound only shrinks: max(mn,0) < mx implies every earlier one.
+__device__ __forceinline__ bool box_hit_fast(V3 lo, V3 hi, const Ray &r, V3 rcp, double bound) {
+    double ax = div_by_const(lo.x - r.o.x, r.d.x, rcp.x), bx = div_by_const(hi.x - r.o.x, r.d.x, rcp.x);
+    double ay = div_by_const(lo.y - r.o.y, r.d.y, rcp.y), by = div_by_const(hi.y - r.o.y, r.d.y, rcp.y);
+    double az = div_by_const(lo.z - r.o.z, r.d.z, rcp.z), bz = div_by_const(hi.z - r.o.z, r.d.z, rcp.z);
+    double mn = hw_max(hw_max(hw_min(ax, bx), hw_min(ay, by)), hw_max(hw_min(az, bz), 0.0));
+    // the +inf keeps mx a number when all three axes are skipped (full interval)
+    double mx = hw_min(hw_min(hw_max(ax, bx), hw_max(ay, by)), hw_min(hw_max(az, bz), kInf));
+    return mn < mx && mn < bound;
+}
+
+// Triangle::raycast's accept/reject decision and hit time (geo/triangle.rs:54-82)
+// without the three barycentric divisions: c_i = n_i / denom is only compared
+// with 0 here, and for denom in [2^-400, 2^400] and n_i either 0 or not below
+// 2^-600 in magnitude the quotient cannot underflow, so `c_i < 0` is `n_i < 0`
+// (NaN and infinite n_i included).  Outside that window the wave falls back to
+// the divisions.  The barycentrics themselves are rebuilt for the winner only.
+__device__ __forceinline__ bool tri_hit_time_signs(V3 v0, V3 v1, V3 v2, const Ray &r, double &t_out) {
+    V3 e01 = v1 - v0, e12 = v2 - v1, e20 = v0 - v2;
+    V3 nt = cross(e01, e12);
+    double denom = dot(nt, nt);
+    double nd = dot(nt, r.d);
+    bool ok = !(nd > 0.0);
+    double t = dot(v0 - r.o, nt) / nd;       // d.dot(nt) has the same products in the same order as nt.dot(d)
+    ok = ok && !(t < 0.0);
+    V3 q = ray_pos(r, t);
+    double n0 = dot(cross(e01, q - v0), nt);
+    double n1 = dot(cross(e12, q - v1), nt);
+    double n2 = dot(cross(e20, q - v2), nt);
+    const double tiny = 0x1p-600;
+    bool window = denom >= 0x1p-400 && denom <= 0x1p400 &&
+                  (n0 == 0.0 || !(__builtin_fabs(n0) < tiny)) && (n1 == 0.0 || !(__builtin_fabs(n1) < tiny)) &&
+                  (n2 == 0.0 || !(__builtin_fabs(n2) < tiny));
+    if (__ballot(!window) != 0) {
+        ok = ok && !(n0 / denom < 0.0) && !(n1 / denom < 0.0) && !(n2 / denom < 0.0);
+    } else {
+        ok = ok && !(n0 < 0.0) && !(n1 < 0.0) && !(n2 < 0.0);
+    }
+    t_out = t;
+    return ok;
+}
+
+// Generic box test with IEEE divisions (any magnitudes).
+__device__ __forceinline__ bool box_hit_div(V3 lo, V3 hi, const Ray &r, double bound) {
+    double mn = -kInf, mx = kInf;
+    bool ok = true;
+#define RTG_AXIS(c)                                                   \
+    {                                                                 \
+        double a = (lo.c - r.o.c) / r.d.c, b = (hi.c - r.o.c) / r.d.c; \
+        if (is_finite(a) && is_finite(b)) {                           \
+            mn = __builtin_fmax(mn, __builtin_fmin(a, b));            \
+            mx = __builtin_fmin(mx, __builtin_fmax(a, b));            \
+            ok = ok && (mn < mx);                                     \
+        }                                                             \
+    }
+    RTG_AXIS(x)
+    RTG_AXIS(y)
+    RTG_AXIS(z)
+#undef RTG_AXIS
+    double lo0 = __builtin_fmax(mn, 0.0);
+    return ok && (lo0 < mx) && (lo0 < bound);
+}
+
+typedef const DevNode __attribute__((address_space(1))) *GNodePtr;
+typedef const DevTri __attribute__((address_space(1))) *GTriPtr;
+
+typedef double vd2 __attribute__((ext_vector_type(2)));
+typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_node_g(GNodePtr p, V3 &lo, V3 &hi, uint4 &tail) {
+    typedef const vd2 __attribute__((address_space(1))) *D2;
+    typedef const vu4 __attribute__((address_space(1))) *U4;
+    D2 q = (D2)p;
+    vd2 a = q[0], b = q[1], c = q[2];
+    vu4 t = ((U4)p)[3];
+    tail.x = t.x;
+    tail.y = t.y;
+    tail.z = t.z;
+    tail.w = t.w;
+    lo = mk(a.x, a.y, b.x);
+    hi = mk(b.y, c.x, c.y);
+}
+__device__ __forceinline__ void load_tri_g(GTriPtr p, V3 &v0, V3 &v1, V3 &v2) {
+    typedef const vd2 __attribute__((address_space(1))) *D2;
+    D2 q = (D2)p;
+    vd2 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    v0 = mk(a.x, a.y, b.x);
+    v1 = mk(b.y, c.x, c.y);
+    v2 = mk(d.x, d.y, e.x);
+}
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Work hand-out: 8 ranges of 64-item chunks, one per XCD label; a wave drains
+// its own range first, then the others in ring order.
+constexpr int kCounterStride = 32;   // one 128-B line per counter
+struct WorkQueue {
+    uint32_t *counters;
+    uint32_t total_chunks;
+    uint32_t per_range;
+    uint32_t range;       // range currently being drained
+    uint32_t tried;       // ranges found empty so far
+    __device__ __forceinline__ bool grab(uint32_t &chunk) {
+        while (tried < 8) {
+            uint32_t begin = range * per_range;
+            uint32_t end = begin + per_range < total_chunks ? begin + per_range : total_chunks;
+            uint32_t got = 0;
+            if ((threadIdx.x & 63u) == 0 && begin < end) got = atomicAdd(counters + range * kCounterStride, 1u);
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (begin < end && begin + got < end) {
+                chunk = begin + got;
+                return true;
+            }
+            range = (range + 1) & 7u;
+            tried++;
+        }
+        return false;
+    }
+};
+
+struct PhasedParams {
+    uint32_t tri_min;     // run a TRI step once this many lanes wait for one
+    uint32_t obj_min;     // same for the between-objects step
+    uint32_t idle_min;    // refill once this many lanes are idle
+};
+
+// STATS builds add per-wave step/lane tallies into work_counters[8*kCounterStride ...] (diagnostics only).
+template <class Source, bool COUNT, bool POINTS, bool STATS = false>
+__global__ __launch_bounds__(kBlock, 4) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
+                                                          uint32_t *work_counters, PhasedParams prm,
+                                                          rtg_hit *out_hits, rtg_point *out_points,
+                                                          rtg_ray_counters *out_counters) {
+    uint32_t st_iter = 0, st_node = 0, st_node_l = 0, st_tri = 0, st_tri_l = 0, st_obj = 0, st_obj_l = 0, st_refill = 0;
+    WorkQueue wq;
+    wq.counters = work_counters;
+    wq.total_chunks = (uint32_t)((n_items + 63) >> 6);
+    wq.per_range = (wq.total_chunks + 7) >> 3;
+    wq.range = blockIdx.x & 7u;
+    wq.tried = 0;
+    bool exhausted = false;
+    uint64_t chunk_base = 0;      // wave-uniform
+    uint32_t chunk_left = 0;      // wave-uniform
+
+    // per-lane state
+    uint32_t phase = PH_IDLE;
+    uint64_t out_index = 0;
+    Ray ray{};                    // outer ray
+    Ray in{};                     // ray in the current object's space
+    V3 rcp = mk(0, 0, 0);
+    bool fast = false;
+    bool best_have = false;
+    double best_t = kInf;
+    uint32_t best_obj = RTG_NONE, best_leaf = RTG_NONE;
+    Holder h;
+    h.has = false;
+    h.t = kInf;
+    h.leaf = RTG_NONE;
+    uint32_t obj_i = 0, cur = 0, end = 0, leaf_cur = 0, leaf_end = 0;
+    GNodePtr nodes = nullptr;
+    GTriPtr tris = nullptr;
+    Counter ctr;
+    ctr.nodes = 0;
+    ctr.tris = 0;
+
+    for (;;) {
+        if (STATS) st_iter++;
+        uint64_t m_idle = __ballot(phase == PH_IDLE);
+        uint32_t n_idle = (uint32_t)__popcll(m_idle);
+        // ---- refill ---------------------------------------------------------------
+        if (!exhausted && (n_idle >= prm.idle_min || n_idle == 64u)) {
+            if (STATS) st_refill++;
+            while (m_idle != 0) {
+                if (chunk_left == 0) {
+                    uint32_t chunk;
+                    if (!wq.grab(chunk)) {
+                        exhausted = true;
+                        break;
+                    }
+                    chunk_base = (uint64_t)chunk << 6;
+                    chunk_left = 64;
+                }
+                uint32_t rank = lane_rank(m_idle);
+                uint32_t n_take = n_idle < chunk_left ? n_idle : chunk_left;
+                if (phase == PH_IDLE && rank < n_take) {
+                    uint64_t item = chunk_base + (64u - chunk_left) + rank;
+                    if (src.make(item, ray, out_index)) {
+                        phase = PH_OBJ;
+                        obj_i = 0;
+                        best_have = false;
+                        best_t = kInf;
+                        best_obj = RTG_NONE;
+                        best_leaf = RTG_NONE;
+                        ctr.nodes = 0;
+                        ctr.tris = 0;
+                    }
+                }
+                chunk_left -= n_take;
+                m_idle = __ballot(phase == PH_IDLE);
+                n_idle = (uint32_t)__popcll(m_idle);
+            }
+        }
+        uint64_t m_node = __ballot(phase == PH_NODE);
+        uint64_t m_tri = __ballot(phase == PH_TRI);
+        uint64_t m_obj = __ballot(phase == PH_OBJ);
+        if ((m_node | m_tri | m_obj) == 0) {
+            if (exhausted) break;
+            continue;   // everything idle but chunks remain: refill on the next turn
+        }
+
+        // ---- between objects: next object, or finish the ray -----------------------
+        if (m_obj != 0 && ((uint32_t)__popcll(m_obj) >= prm.obj_min || (m_node | m_tri) == 0)) {
+            if (STATS) {
+                st_obj++;
+                st_obj_l += (uint32_t)__popcll(m_obj);
+            }
+            while (phase == PH_OBJ) {
+                if (obj_i >= s.n_objects) {
+                    SceneHit sh;
+                    sh.have = best_have;
+                    sh.t = best_t;
+                    sh.object = best_obj;
+                    sh.leaf = best_leaf;
+                    if (out_hits) {
+                        uint64_t tb = __double_as_longlong(sh.have ? sh.t : kInf);
+                        uint4 v;
+                        v.x = sh.have ? sh.object : RTG_NONE;
+                        v.y = sh.have ? sh.leaf : RTG_NONE;
+                        v.z = (uint32_t)tb;
+                        v.w = (uint32_t)(tb >> 32);
+                        *reinterpret_cast<uint4 *>(out_hits + out_index) = v;
+                    }
+                    if (POINTS) scene_point(s, ray, sh, out_points[out_index]);
+                    if (COUNT) {
+                        out_counters[out_index].nodes_visited = ctr.nodes;
+                        out_counters[out_index].tris_tested = ctr.tris;
+                    }
+                    phase = PH_IDLE;
+                    break;
+                }
+                const DevObject &o = s.objects[obj_i];
+                in = inner_ray(o, ray);
+                bool some = false;
+                double t = 0.0;
+                if (o.kind == RTG_SPHERE) {
+                    some = sphere_hit_time(ld3(o.sphere_center), o.sphere_radius, in, t);
+                } else if (o.kind == RTG_PLANE) {
+                    some = plane_hit_time(ld3(o.plane_position), ld3(o.plane_tan1), ld3(o.plane_tan2), in, t);
+                } else if (o.kind == RTG_MESH && o.mesh.n_nodes != 0) {
+                    nodes = (GNodePtr)o.mesh.tnodes;
+                    tris = (GTriPtr)o.mesh.tris;
+                    end = o.mesh.n_nodes;
+                    cur = 0;
+                    h.has = false;
+                    h.t = kInf;
+                    h.leaf = RTG_NONE;
+                    fast = o.mesh.fast_div_ok != 0 && fast_div_ray_ok(in);
+                    rcp = mk(1.0 / in.d.x, 1.0 / in.d.y, 1.0 / in.d.z);
+                    phase = PH_NODE;
+                    break;
+                }
+                if (some) {
+                    bool better = !best_have || (!is_nan(best_t) && (is_nan(t) || best_t > t));
+                    if (better) {
+                        best_have = true;
+                        best_t = t;
+                        best_obj = obj_i;
+                        best_leaf = RTG_NONE;
+                    }
+                }
+                obj_i++;
+            }
+            m_node = __ballot(phase == PH_NODE);
+            m_tri = __ballot(phase == PH_TRI);
+        }
+
+        // ---- one box test per lane ---------------------------------------------------
+        if (m_node != 0) {
+            if (STATS) {
+                st_node++;
+                st_node_l += (uint32_t)__popcll(m_node);
+            }
+            bool slow_any = __ballot(phase == PH_NODE && !fast) != 0;
+            if (phase == PH_NODE) {
+                V3 lo, hi;
+                uint4 tail;
+                load_node_g(nodes + cur, lo, hi, tail);
+                if (COUNT) ctr.nodes++;
+                double bound = holder_bound(h);
+                bool go = slow_any ? box_hit_div(lo, hi, in, bound) : box_hit_fast(lo, hi, in, rcp, bound);
+                if (go) {
+                    cur = cur + 1;
+                    if (tail.w != 0) {
+                        leaf_cur = tail.z;
+                        leaf_end = tail.z + tail.w;
+                        phase = PH_TRI;
+                    }
+                } else {
+                    cur = tail.x;
+                }
+                if (phase == PH_NODE && cur >= end) phase = PH_OBJ + 4;   // traversal finished (resolved below)
+            }
+            m_tri = __ballot(phase == PH_TRI);
+        }
+
+        // ---- one triangle per waiting lane ----------------------------------------------
+        if (m_tri != 0 && ((uint32_t)__popcll(m_tri) >= prm.tri_min || __ballot(phase == PH_NODE) == 0)) {
+            if (STATS) {
+                st_tri++;
+                st_tri_l += (uint32_t)__popcll(m_tri);
+            }
+            if (phase == PH_TRI) {
+                V3 v0, v1, v2;
+                load_tri_g(tris + leaf_cur, v0, v1, v2);
+                double t;
+                bool some = tri_hit_time_signs(v0, v1, v2, in, t);
+                holder_add(h, some, t, leaf_cur);
+                if (COUNT) ctr.tris++;
+                leaf_cur++;
+                if (leaf_cur >= leaf_end) phase = cur >= end ? PH_OBJ + 4 : PH_NODE;
+            }
+        }
+
+        // ---- a finished traversal reports to the scene-level minimum ------------------------
+        if (phase == PH_OBJ + 4) {
+            if (h.has) {
+                bool better = !best_have || (!is_nan(best_t) && (is_nan(h.t) || best_t > h.t));
+                if (better) {
+                    best_have = true;
+                    best_t = h.t;
+                    best_obj = obj_i;
+                    best_leaf = h.leaf;
+                }
+            }
+            obj_i++;
+            phase = PH_OBJ;
+        }
+    }
+    if (STATS && (threadIdx.x & 63u) == 0) {
+        uint32_t *st = work_counters + 8 * kCounterStride;
+        atomicAdd(st + 0, st_iter);
+        atomicAdd(st + 1, st_node);
+        atomicAdd(st + 2, st_node_l);
+        atomicAdd(st + 3, st_tri);
+        atomicAdd(st + 4, st_tri_l);
+        atomicAdd(st + 5, st_obj);
+        atomicAdd(st + 6, st_obj_l);
+        atomicAdd(st + 7, st_refill);
+        atomicAdd(st + 8, 1u);
+    }
+}
+
+// ---- launchers -------------------------------------------------------------------------
+template <class Source>
+static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Source &src, uint64_t n_items,
+                                uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits,
+                                rtg_point *out_points, rtg_ray_counters *out_counters) {
+    if (n_items == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(work_counters, 0, (8 * kCounterStride + 16) * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    uint64_t chunks = (n_items + 63) >> 6;
+    uint64_t want = (chunks + 3) / 4;
+    uint32_t grid = (uint32_t)(want < tune.max_blocks ? want : tune.max_blocks);
+    if (grid == 0) grid = 1;
+    PhasedParams prm{tune.tri_min, tune.obj_min, tune.idle_min};
+    dim3 g(grid), b(kBlock);
+    bool count = out_counters != nullptr, points = out_points != nullptr;
+    if (tune.stats && !count && !points)
+        hipLaunchKernelGGL((k_trace_phased<Source, false, false, true>), g, b, 0, stream, s, src, n_items, work_counters,
+                           prm, out_hits, out_points, out_counters);
+    else if (count && points)
+        hipLaunchKernelGGL((k_trace_phased<Source, true, true>), g, b, 0, stream, s, src, n_items, work_counters, prm,
+                           out_hits, out_points, out_counters);
+    else if (count)
+        hipLaunchKernelGGL((k_trace_phased<Source, true, false>), g, b, 0, stream, s, src, n_items, work_counters, prm,
+                           out_hits, out_points, out_counters);
+    else if (points)
+        hipLaunchKernelGGL((k_trace_phased<Source, false, true>), g, b, 0, stream, s, src, n_items, work_counters, prm,
+                           out_hits, out_points, out_counters);
+    else
+        hipLaunchKernelGGL((k_trace_phased<Source, false, false>), g, b, 0, stream, s, src, n_items, work_counters, prm,
+                           out_hits, out_points, out_counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_primary_phased(hipStream_t stream, const DevScene &s, const rtg_view &view, uint32_t width,
+                                        uint32_t height, rtg_rect tile, uint32_t *work_counters,
+                                        const PhasedTuning &tune, rtg_hit *out_hits, rtg_point *out_points,
+                                        rtg_ray_counters *out_counters) {
+    PrimarySource src;
+    src.view = view;
+    src.width = width;
+    src.height = height;
+    src.tile = tile;
+    src.tiles_x = (tile.w + 7) / 8;
+    uint64_t tiles = (uint64_t)src.tiles_x * ((tile.h + 7) / 8);
+    return launch_phased(stream, s, src, tiles * 64, work_counters, tune, out_hits, out_points, out_counters);
+}
+
+hipError_t launch_trace_phased(hipStream_t stream, const DevScene &s, const double *rays6, uint64_t n,
+                               uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits,
+                               rtg_point *out_points, rtg_ray_counters *out_counters) {
+    BatchSource src;
+    src.rays6 = rays6;
+    src.n = n;
+    return launch_phased(stream, s, src, n, work_counters, tune, out_hits, out_points, out_counters);
+}
+
+} // namespace rtg

@@ -102,6 +102,7 @@ _sig(lib.rtg_ctx_set_stream, C.c_int, _vp, _vp)
 _sig(lib.rtg_ctx_get_stream, _vp, _vp)
 _sig(lib.rtg_ctx_synchronize, C.c_int, _vp)
 _sig(lib.rtg_ctx_set_option, C.c_int, _vp, C.c_char_p, C.c_int64)
+_sig(lib.rtg_ctx_debug_stats, C.c_int, _vp, C.POINTER(C.c_uint32))
 _sig(lib.rtg_transform_from_forward, C.c_int, C.POINTER(C.c_double), C.POINTER(Transform))
 _sig(lib.rtg_mesh_create, C.c_int, _vp, C.POINTER(Bvh), C.POINTER(_vp))
 _sig(lib.rtg_mesh_destroy, None, _vp)
@@ -312,6 +313,13 @@ class Context:
 
     def synchronize(self):
         self._check(lib.rtg_ctx_synchronize(self._h))
+
+    def debug_stats(self):
+        out = (C.c_uint32 * 16)()
+        self._check(lib.rtg_ctx_debug_stats(self._h, out))
+        names = ["iterations", "node_steps", "node_lanes", "tri_steps", "tri_lanes", "obj_steps", "obj_lanes",
+                 "refills", "waves"]
+        return dict(zip(names, list(out)))
 
     def mesh(self, bvh):
         return Mesh(self, bvh)

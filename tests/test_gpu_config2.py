@@ -17,13 +17,13 @@ def test_config2_one_million_triangles_1080p(gpu_ctx):
     pair = scenes.Pair(gpu_ctx, objs, {0: bvh})
     w, h = 1920, 1080
     c_hits, _, c_ctr = pair.cpu.render_primary(view, w, h, counters=True)
-    for traversal in (0, 1):
+    for traversal in (0, 1, 2):
         gpu_ctx.set_option("traversal", traversal)
         g_hits, _, g_ctr = pair.gpu.render_primary(view, w, h, counters=True)
         bad = scenes.hit_mismatches(g_hits, c_hits)
         assert bad.size == 0, f"traversal {traversal}: {bad.size} mismatching pixels of {w * h}"
         assert np.array_equal(g_ctr, c_ctr)
-    gpu_ctx.set_option("traversal", 0)
+    gpu_ctx.set_option("traversal", 2)
     covered = (g_hits["leaf"] != rtg.RTG_NONE).mean()
     assert covered > 0.5, covered
     # size-independent properties: every reported leaf really contains its hit point, and

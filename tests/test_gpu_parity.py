@@ -13,7 +13,7 @@ from raytracer_amd import rtg
 
 pytestmark = pytest.mark.gpu
 
-TRAVERSALS = [0, 1]   # short stack, threaded
+TRAVERSALS = [0, 1, 2]   # short stack, threaded, phased threaded (persistent, reciprocal box test)
 
 
 def _assert_hits_equal(g, c):
@@ -74,7 +74,7 @@ def test_mesh_scene_primary(gpu_ctx, traversal, with_normals):
     assert np.array_equal(g_ctr["nodes_visited"], c_ctr["nodes_visited"])
     assert np.array_equal(g_ctr["tris_tested"], c_ctr["tris_tested"])
     assert (g_hits["object"] == 2).mean() > 0.3
-    gpu_ctx.set_option("traversal", 0)
+    gpu_ctx.set_option("traversal", 2)
 
 
 @pytest.mark.parametrize("traversal", TRAVERSALS)
@@ -96,7 +96,7 @@ def test_incoherent_batch_rays(gpu_ctx, traversal):
     perm, sorted_rays = rtg.sort_rays(bvh.bounds(), rays)
     s_hits, _, _ = pair.gpu.trace(sorted_rays)
     assert scenes.same_hits(s_hits, g_hits[perm])
-    gpu_ctx.set_option("traversal", 0)
+    gpu_ctx.set_option("traversal", 2)
 
 
 @pytest.mark.parametrize("traversal", TRAVERSALS)
@@ -132,7 +132,7 @@ def test_quirks_nan_inf_ties_and_degenerates(gpu_ctx, traversal):
     _assert_hits_equal(g_hits, c_hits)
     _assert_points_equal(g_pts, c_pts)
     assert np.isnan(g_hits["t"]).any(), "the degenerate triangles should produce NaN-time hits"
-    gpu_ctx.set_option("traversal", 0)
+    gpu_ctx.set_option("traversal", 2)
 
 
 def test_deep_tree_uses_every_stack_tier(gpu_ctx):
@@ -157,7 +157,7 @@ def test_deep_tree_uses_every_stack_tier(gpu_ctx):
         g_hits, _, g_ctr = pair.gpu.trace(rays, counters=True)
         _assert_hits_equal(g_hits, c_hits)
         assert np.array_equal(g_ctr, c_ctr)
-    gpu_ctx.set_option("traversal", 0)
+    gpu_ctx.set_option("traversal", 2)
 
 
 def test_empty_inputs(gpu_ctx):
