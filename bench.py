@@ -48,7 +48,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from raytracer_amd import rtg
+    from raytracer_amd import rtg, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -84,7 +84,7 @@ def main():
     n_rays = WIDTH * HEIGHT
     tile = (0, 0, WIDTH, HEIGHT)
     hits = torch.empty(n_rays * 16, dtype=torch.uint8, device=dev)
-    gathered = [torch.empty_like(hits) for _ in range(world)] if (world > 1 and rank == 0) else None
+    sizes = [hits.numel()] * world
 
     def step(i, ev=None):
         frame = i * world + rank
@@ -94,7 +94,7 @@ def main():
         if ev is not None:
             ev[1].record(stream)
         if world > 1:
-            dist.gather(hits, gathered, dst=0)
+            shard.gather_to_root(hits, sizes, dst=0)      # RCCL gather of the finished framebuffers to rank 0
 
     for i in range(args.warmup):
         step(i)

@@ -187,6 +187,13 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value);
  * waves (no reference counterpart). */
 int rtg_ctx_debug_stats(rtg_ctx *ctx, uint32_t out[16]);
 
+/* Self-test (no reference counterpart): compares the reciprocal-based quotient
+ * the box test of traversal 2 uses with the hardware IEEE division on n_pairs
+ * generated (x, d) pairs of one family (0 random, 1 small integers, 2 quotients
+ * next to representable numbers, 3 special denominators).  out[0] = number of
+ * pairs whose quotients differ in any bit, out[1], out[2] = bits of one such pair. */
+int rtg_selftest_division(rtg_ctx *ctx, uint64_t seed, uint64_t n_pairs, uint32_t family, uint64_t out[3]);
+
 /* Restates `Transform::from(Mat4)` (src/geo/transform.rs:51-58) with the
  * inverse formulas of src/math/mat.rs:80-87,100-154 for callers that only hold
  * the forward matrix. */

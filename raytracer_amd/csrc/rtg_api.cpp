@@ -414,6 +414,22 @@ int rtg_ctx_debug_stats(rtg_ctx *ctx, uint32_t out[16]) {
     return RTG_OK;
 }
 
+int rtg_selftest_division(rtg_ctx *ctx, uint64_t seed, uint64_t n_pairs, uint32_t family, uint64_t out[3]) {
+    if (!ctx || !out) return fail(ctx, RTG_E_INVALID, "null argument");
+    if (family > 3) return fail(ctx, RTG_E_INVALID, "family must be 0..3");
+    int rc = bind_device(ctx);
+    if (rc != RTG_OK) return rc;
+    void *d = nullptr;
+    if ((rc = scratch_get(ctx, "selftest", 3 * sizeof(uint64_t), &d)) != RTG_OK) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(d, 0, 3 * sizeof(uint64_t), ctx->stream));
+    const uint32_t per_thread = 1024, blocks = (uint32_t)((n_pairs + 256ull * per_thread - 1) / (256ull * per_thread));
+    if (blocks == 0 || blocks > (1u << 20)) return fail(ctx, RTG_E_LIMIT, "n_pairs out of range");
+    HIP_TRY(ctx, launch_selftest_div(ctx->stream, seed, blocks, per_thread, family, (uint64_t *)d));
+    HIP_TRY(ctx, hipMemcpyAsync(out, d, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTG_OK;
+}
+
 int rtg_transform_from_forward(const double forward[16], rtg_transform *out) {
     if (!forward || !out) return fail(nullptr, RTG_E_INVALID, "null argument");
     std::memcpy(out->forward, forward, sizeof(out->forward));

@@ -33,4 +33,7 @@ hipError_t launch_trace_phased(hipStream_t stream, const DevScene &s, const doub
                                uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits,
                                rtg_point *out_points, rtg_ray_counters *out_counters);
 
+hipError_t launch_selftest_div(hipStream_t stream, uint64_t seed, uint32_t blocks, uint32_t per_thread, uint32_t family,
+                               uint64_t *out3);
+
 } // namespace rtg

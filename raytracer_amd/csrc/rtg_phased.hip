@@ -458,6 +458,63 @@ __global__ __launch_bounds__(kBlock, 4) void k_trace_phased(DevScene s, Source s
     }
 }
 
+// ---- self-test of div_by_const against the hardware division ----------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t &st) {
+    uint64_t z = (st += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// family 0: random significands, exponents across the whole fast window
+// family 1: small-integer numerators and denominators (exact and repeating quotients)
+// family 2: x = RN(q*d) +- a few ulps (quotients next to representable numbers and to midpoints)
+// family 3: denominators with all-ones / single-bit significands
+__global__ void k_selftest_div(uint64_t seed, uint32_t per_thread, uint32_t family, uint64_t *out) {
+    uint64_t st = seed ^ ((uint64_t)(blockIdx.x * blockDim.x + threadIdx.x) * 0xD1B54A32D192ED03ull);
+    uint64_t bad = 0;
+    for (uint32_t i = 0; i < per_thread; i++) {
+        uint64_t a = mix64(st), b = mix64(st), c = mix64(st);
+        double x, d;
+        if (family == 0) {
+            int ex = (int)(a % 1001) - 600, ed = (int)(b % 201) - 100;           // 2^-600..2^400, 2^-100..2^100
+            x = __longlong_as_double((int64_t)((c & 0x800FFFFFFFFFFFFFull) | ((uint64_t)(ex + 1023) << 52)));
+            d = __longlong_as_double((int64_t)((mix64(st) & 0x800FFFFFFFFFFFFFull) | ((uint64_t)(ed + 1023) << 52)));
+        } else if (family == 1) {
+            x = (double)(int64_t)(a % 200001) - 100000.0;
+            d = (double)(int64_t)(b % 4001) - 2000.0;
+            if (d == 0.0) d = 3.0;
+        } else if (family == 2) {
+            double q = __longlong_as_double((int64_t)((a & 0x800FFFFFFFFFFFFFull) | ((uint64_t)(1023 + (int)(a >> 60) - 8) << 52)));
+            d = __longlong_as_double((int64_t)((b & 0x800FFFFFFFFFFFFFull) | ((uint64_t)(1023 + (int)(b >> 60) - 8) << 52)));
+            x = q * d;
+            int64_t bits = __double_as_longlong(x) + (int64_t)(c % 7) - 3;
+            x = __longlong_as_double(bits);
+        } else {
+            uint64_t mant = (b & 1) ? 0x000FFFFFFFFFFFFFull : (1ull << (b % 52));
+            if (b & 2) mant ^= (mix64(st) & 0xFF);
+            int ed = (int)((b >> 8) % 201) - 100;
+            d = __longlong_as_double((int64_t)((b & 0x8000000000000000ull) | mant | ((uint64_t)(ed + 1023) << 52)));
+            int ex = (int)(a % 1001) - 600;
+            x = __longlong_as_double((int64_t)((c & 0x800FFFFFFFFFFFFFull) | ((uint64_t)(ex + 1023) << 52)));
+        }
+        double r = 1.0 / d;
+        double fast = div_by_const(x, d, r);
+        double ref = x / d;
+        if (__double_as_longlong(fast) != __double_as_longlong(ref)) {
+            bad++;
+            out[1] = (uint64_t)__double_as_longlong(x);
+            out[2] = (uint64_t)__double_as_longlong(d);
+        }
+    }
+    if (bad) atomicAdd((unsigned long long *)out, (unsigned long long)bad);
+}
+
+hipError_t launch_selftest_div(hipStream_t stream, uint64_t seed, uint32_t blocks, uint32_t per_thread, uint32_t family,
+                               uint64_t *out3) {
+    hipLaunchKernelGGL(k_selftest_div, dim3(blocks), dim3(256), 0, stream, seed, per_thread, family, out3);
+    return hipGetLastError();
+}
+
 // ---- launchers -------------------------------------------------------------------------
 template <class Source>
 static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Source &src, uint64_t n_items,

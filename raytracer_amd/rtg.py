@@ -103,6 +103,7 @@ _sig(lib.rtg_ctx_get_stream, _vp, _vp)
 _sig(lib.rtg_ctx_synchronize, C.c_int, _vp)
 _sig(lib.rtg_ctx_set_option, C.c_int, _vp, C.c_char_p, C.c_int64)
 _sig(lib.rtg_ctx_debug_stats, C.c_int, _vp, C.POINTER(C.c_uint32))
+_sig(lib.rtg_selftest_division, C.c_int, _vp, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64))
 _sig(lib.rtg_transform_from_forward, C.c_int, C.POINTER(C.c_double), C.POINTER(Transform))
 _sig(lib.rtg_mesh_create, C.c_int, _vp, C.POINTER(Bvh), C.POINTER(_vp))
 _sig(lib.rtg_mesh_destroy, None, _vp)
@@ -313,6 +314,12 @@ class Context:
 
     def synchronize(self):
         self._check(lib.rtg_ctx_synchronize(self._h))
+
+    def selftest_division(self, n_pairs, family, seed=1):
+        """(mismatches, x_bits, d_bits) of the reciprocal-based quotient vs the hardware division."""
+        out = (C.c_uint64 * 3)()
+        self._check(lib.rtg_selftest_division(self._h, seed, n_pairs, family, out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def debug_stats(self):
         out = (C.c_uint32 * 16)()

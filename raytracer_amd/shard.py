@@ -1,0 +1,131 @@
+"""Sharding of the ray-cast path over the GPUs of one node, one process per GPU.
+
+The path has no exchange step during compute: every pixel / ray is independent (the reference's pixel pass,
+src/render/renderer.rs:147-149, maps over `&self`) and frames are independent given `time` (src/bin/local.rs:42-50;
+the reference itself fans frames out over HTTP workers, scripts/request_all.sh:2).  So the scene/BVH is replicated on
+every GPU and only finished framebuffer pieces move: one gather to the root per frame, over RCCL (backend "nccl")
+on GPUs or gloo on CPUs -- the functions here only see `torch.distributed`.
+
+Two partitions are offered:
+
+* frame mode  -- frame f is rendered by rank f mod world (weak scaling: a sequence renders `world` frames at once);
+* tile mode   -- one frame is cut into horizontal strips of whole 8-row wave tiles, dealt round-robin
+                 (`interleave` strips per rank) so sky-heavy and geometry-heavy rows are spread evenly.
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+Rect = Tuple[int, int, int, int]   # x0, y0, w, h
+
+
+def frame_owner(frame: int, world: int) -> int:
+    return frame % world
+
+
+def frames_of_rank(rank: int, world: int, n_frames: int) -> List[int]:
+    return list(range(rank, n_frames, world))
+
+
+def tile_strips(width: int, height: int, world: int, interleave: int = 4, tile_rows: int = 8) -> List[List[Rect]]:
+    """Per-rank list of full-width strips.  Strip heights are multiples of `tile_rows` (except the last strip of the
+    frame); strip s goes to rank s % world; about `interleave` strips per rank."""
+    if world <= 0:
+        raise ValueError("world must be positive")
+    n_tile_rows = (height + tile_rows - 1) // tile_rows
+    n_strips = max(1, min(n_tile_rows, world * max(1, interleave)))
+    per = [n_tile_rows // n_strips + (1 if i < n_tile_rows % n_strips else 0) for i in range(n_strips)]
+    out: List[List[Rect]] = [[] for _ in range(world)]
+    y = 0
+    for s, rows in enumerate(per):
+        h = min(rows * tile_rows, height - y)
+        if h > 0:
+            out[s % world].append((0, y, width, h))
+        y += h
+    assert y == height
+    return out
+
+
+def rect_pixels(rects: Sequence[Rect]) -> int:
+    return sum(w * h for _, _, w, h in rects)
+
+
+def gather_to_root(local: torch.Tensor, sizes: Sequence[int], dst: int = 0, group=None):
+    """Gathers each rank's flat buffer (`sizes[r]` elements on rank r) to rank `dst`.
+    Equal sizes use one `gather` collective; unequal sizes use grouped point-to-point sends, which is what RCCL
+    does for gather anyway.  Returns the list of per-rank tensors on `dst`, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert local.numel() == sizes[rank], (local.numel(), sizes[rank])
+    if len(set(sizes)) == 1:
+        bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+        dist.gather(local, bufs, dst=dst, group=group)
+        return bufs
+    if rank == dst:
+        bufs = [local if r == dst else torch.empty(sizes[r], dtype=local.dtype, device=local.device) for r in range(world)]
+        ops = [dist.P2POp(dist.irecv, bufs[r], r, group) for r in range(world) if r != dst and sizes[r] > 0]
+    else:
+        bufs = None
+        ops = [dist.P2POp(dist.isend, local, dst, group)] if sizes[rank] > 0 else []
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return bufs
+
+
+def assemble_frame(width: int, height: int, rects_per_rank: Sequence[Sequence[Rect]], buffers: Sequence[torch.Tensor],
+                   channels: int) -> torch.Tensor:
+    """Places every rank's strips (concatenated in rect order, `channels` elements per pixel) into a
+    (height, width, channels) frame."""
+    frame = torch.empty((height, width, channels), dtype=buffers[0].dtype, device=buffers[0].device)
+    for rects, buf in zip(rects_per_rank, buffers):
+        off = 0
+        for x0, y0, w, h in rects:
+            n = w * h * channels
+            frame[y0:y0 + h, x0:x0 + w, :] = buf[off:off + n].view(h, w, channels)
+            off += n
+        assert off == buf.numel()
+    return frame
+
+
+def render_frame_tiles(render_rect, width: int, height: int, channels: int, dtype, device, interleave: int = 4,
+                       dst: int = 0, group=None):
+    """Tile mode: this rank renders its strips with `render_rect(rect, out_flat_tensor)` and the strips are gathered
+    on `dst`, which returns the assembled (height, width, channels) frame; other ranks return None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    plan = tile_strips(width, height, world, interleave)
+    sizes = [rect_pixels(r) * channels for r in plan]
+    local = torch.empty(sizes[rank], dtype=dtype, device=device)
+    off = 0
+    for rect in plan[rank]:
+        n = rect[2] * rect[3] * channels
+        render_rect(rect, local[off:off + n])
+        off += n
+    bufs = gather_to_root(local, sizes, dst, group)
+    if rank != dst:
+        return None
+    return assemble_frame(width, height, plan, bufs, channels)
+
+
+def render_sequence_frames(render_frame, n_frames: int, frame_elems: int, dtype, device, dst: int = 0, group=None):
+    """Frame mode: rank r renders frames r, r+world, ...; after each round the `world` frames are gathered on `dst`.
+    `render_frame(frame_index, out_flat_tensor)`.  Returns {frame index: tensor} on `dst`, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    out = {} if rank == dst else None
+    local = torch.empty(frame_elems, dtype=dtype, device=device)
+    for base in range(0, n_frames, world):
+        f = base + rank
+        live = [base + r < n_frames for r in range(world)]
+        if live[rank]:
+            render_frame(f, local)
+        sizes = [frame_elems if live[r] else 0 for r in range(world)]
+        mine = local if live[rank] else local[:0]
+        bufs = gather_to_root(mine, sizes, dst, group)
+        if rank == dst:
+            for r in range(world):
+                if live[r]:
+                    out[base + r] = bufs[r].clone()
+    return out

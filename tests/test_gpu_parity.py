@@ -265,3 +265,13 @@ def test_device_f64_div_and_sqrt_are_correctly_rounded(gpu_ctx):
     _assert_points_equal(g_pts, c_pts)
     assert (g_hits["object"] == 0).all()
     del math
+
+
+@pytest.mark.parametrize("family", [0, 1, 2, 3])
+def test_reciprocal_quotient_equals_ieee_division(gpu_ctx, family):
+    """The phased kernel's box test replaces x/d by two FMA refinements of x*(1/d); every bit must agree with the
+    hardware division over the whole magnitude window the kernel admits (2^28 pairs per family)."""
+    import struct
+    bad, xb, db = gpu_ctx.selftest_division(1 << 28, family, seed=20261111 + family)
+    x, d = struct.unpack("<d", struct.pack("<Q", xb))[0], struct.unpack("<d", struct.pack("<Q", db))[0]
+    assert bad == 0, f"family {family}: {bad} quotients differ, e.g. x={x!r} d={d!r}"

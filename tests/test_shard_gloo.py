@@ -1,0 +1,117 @@
+"""CPU, world_size 2 over gloo: the sharding / gather logic of the multi-GPU path, with the oracle standing in for
+the GPU renderer.  The gathered frame must be byte-identical to the single-process frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from raytracer_amd import shard  # noqa: E402
+
+
+def test_tile_strips_cover_the_frame_once():
+    for (w, h, world, inter) in [(64, 64, 2, 4), (1920, 1080, 8, 4), (33, 7, 4, 2), (16, 8, 8, 4), (100, 1000, 3, 1)]:
+        plan = shard.tile_strips(w, h, world, inter)
+        assert len(plan) == world
+        cover = np.zeros((h, w), dtype=np.int32)
+        for rects in plan:
+            for x0, y0, rw, rh in rects:
+                assert x0 == 0 and rw == w and (y0 % 8 == 0)
+                cover[y0:y0 + rh, x0:x0 + rw] += 1
+        assert (cover == 1).all()
+        sizes = [shard.rect_pixels(r) for r in plan]
+        if h >= 8 * world * inter:
+            assert max(sizes) - min(sizes) <= 8 * w * inter
+    assert shard.frames_of_rank(1, 4, 10) == [1, 5, 9] and shard.frame_owner(9, 4) == 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import orc
+        import scenes
+        from raytracer_amd import rtg
+        w, h = 96, 72
+        # every rank builds the same (replicated) scene
+        tris, xform = scenes.terrain(24, 24, seed=7)
+        bvh = rtg.HostBvh(tris)
+        objs, lights, view = scenes.mesh_scene_objects(xform, time=10)
+        pair = scenes.Pair(None, objs, {2: bvh})
+
+        def render_rect(rect, out):                      # 16-byte hit records as bytes
+            hits, _, _ = pair.cpu.render_primary(view, w, h, tile=rect, threads=1)
+            out.copy_(torch.from_numpy(np.frombuffer(hits.tobytes(), dtype=np.uint8).copy()))
+
+        frame = shard.render_frame_tiles(render_rect, w, h, 16, torch.uint8, "cpu", interleave=3)
+        ok_tiles = True
+        if rank == 0:
+            full, _, _ = pair.cpu.render_primary(view, w, h, threads=1)
+            ok_tiles = frame.numpy().tobytes() == full.tobytes()
+
+        def render_frame(f, out):                        # frame mode: the light orbit changes per frame
+            o2, l2, v2 = scenes.mesh_scene_objects(xform, time=f)
+            rgb, c8, _ = pair.cpu.render_frame(v2, l2, 40, 30, max_depth=2, threads=1)
+            out.copy_(torch.from_numpy(c8.reshape(-1).copy()))
+
+        frames = shard.render_sequence_frames(render_frame, 5, 40 * 30 * 4, torch.uint8, "cpu")
+        ok_frames = True
+        if rank == 0:
+            assert sorted(frames) == [0, 1, 2, 3, 4]
+            for f in range(5):
+                o2, l2, v2 = scenes.mesh_scene_objects(xform, time=f)
+                _, c8, _ = pair.cpu.render_frame(v2, l2, 40, 30, max_depth=2, threads=1)
+                ok_frames = ok_frames and frames[f].numpy().tobytes() == c8.tobytes()
+            with open(result_path, "w") as fh:
+                fh.write(f"{int(ok_tiles)} {int(ok_frames)}")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_gather_equals_single_process(tmp_path):
+    result = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(2, _free_port(), str(result)), nprocs=2, join=True)
+    assert result.read_text() == "1 1"
+
+
+def _worker_unequal(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sizes = [5, 0, 9][:world]
+        local = torch.arange(sizes[rank], dtype=torch.int32) + 100 * rank
+        bufs = shard.gather_to_root(local, sizes)
+        if rank == 0:
+            ok = all(torch.equal(bufs[r], torch.arange(sizes[r], dtype=torch.int32) + 100 * r) for r in range(world))
+            with open(result_path, "w") as fh:
+                fh.write(str(int(ok)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_unequal_and_empty_shards(tmp_path):
+    result = tmp_path / "result.txt"
+    mp.spawn(_worker_unequal, args=(3, _free_port(), str(result)), nprocs=3, join=True)
+    assert result.read_text() == "1"
