@@ -78,6 +78,38 @@ typedef struct {
     uint32_t root;
 } rtg_bvh;
 
+/* One cubic triangular patch, `Trispline` (src/trispline.rs:55-66): the ten
+ * power-basis coefficients of position(t,u) = sum m_ij t^i u^j in the order
+ * m00, m01, m02, m03, m10, m11, m12, m20, m21, m30; domain t,u >= 0, t+u <= 1. */
+typedef struct {
+    double m[10][3];
+} rtg_trispline;
+
+/* What a BVH leaf of a patch mesh stands for: a flat facet of patch `patch`
+ * whose three corners sit at the (t,u) parameters `tu` (the facet's vertex
+ * positions are the rtg_tri of the same leaf). */
+typedef struct {
+    double tu[3][2];
+    uint32_t patch;
+    uint32_t _pad;
+} rtg_patch_leaf;
+
+/* A set of patches behind a facet BVH.  The reference evaluates patches but has
+ * no ray/patch intersection (src/trispline.rs:161-181), so the intersection is
+ * this library's definition: a leaf's flat facet is tested like any triangle
+ * (src/geo/triangle.rs:54-82); when it is hit, (t,u,time) start from the
+ * facet's barycentric interpolation and hit time and take `newton_steps`
+ * Newton steps on position(t,u) = orig + dir*time (Jacobian from ddt, ddu,
+ * -dir, solved by Cramer's rule); the hit is accepted when the final point is
+ * inside the patch domain, time >= 0 and the squared residual is at most
+ * 1e-20 * (|m10|^2 + |m01|^2).  Normals are normalize(ddt x ddu). */
+typedef struct {
+    const rtg_trispline *patches;
+    uint64_t n_patches;
+    const rtg_patch_leaf *leaf_info; /* one per BVH leaf, in leaf order */
+    uint32_t newton_steps;
+} rtg_patch_set;
+
 /* `Material` (src/render/material.rs:3-7). */
 typedef struct {
     double diffuse[3];
@@ -206,6 +238,10 @@ int rtg_transform_from_forward(const double forward[16], rtg_transform *out);
  * bounds, acyclic, every node reachable at most once). */
 int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out);
 void rtg_mesh_destroy(rtg_mesh *mesh);
+/* A facet BVH whose leaves stand for trispline patches (object kind
+ * RTG_PATCHES); `bvh` is the flattened tree over the facets, built like any
+ * mesh.  No reference counterpart for the intersection (see rtg_patch_set). */
+int rtg_mesh_create_patches(rtg_ctx *ctx, const rtg_bvh *bvh, const rtg_patch_set *patches, rtg_mesh **out);
 /* `Bvh::bounds` (src/tree/bvh.rs:134-136): lo[3], hi[3] of the root. */
 int rtg_mesh_bounds(const rtg_mesh *mesh, double out_lo_hi[6]);
 

@@ -503,9 +503,96 @@ struct orc_bvh {
     std::vector<double> normals;     // empty or 9 per leaf
     std::vector<uint32_t> leaf_source;
     uint32_t root = 0;
+    // trispline patch set (empty for plain triangle meshes)
+    std::vector<rtg_trispline> patches;
+    std::vector<rtg_patch_leaf> leaf_info;
+    uint32_t newton_steps = 0;
 };
 
 namespace {
+// ---- trispline.rs (orphan file, written against glam::DVec3) ----------------------
+// glam semantics: dot = (x*x' + y*y') + z*z' (no leading 0.0), normalize = v * (1/length).
+double g_dot(V3 a, V3 b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+double g_length(V3 a) { return std::sqrt(g_dot(a, a)); }
+V3 g_normalize(V3 a) { return a * (1.0 / g_length(a)); }
+V3 smul(double s, V3 a) { return mk(s * a[0], s * a[1], s * a[2]); }
+
+struct Trispline {                      // trispline.rs:55-66, coefficient order of rtg_trispline
+    V3 m00, m01, m02, m03, m10, m11, m12, m20, m21, m30;
+};
+Trispline trispline_from_c(const rtg_trispline &c) {
+    auto v = [&](int i) { return mk(c.m[i][0], c.m[i][1], c.m[i][2]); };
+    return Trispline{v(0), v(1), v(2), v(3), v(4), v(5), v(6), v(7), v(8), v(9)};
+}
+void trispline_to_c(const Trispline &t, rtg_trispline &c) {
+    const V3 *src[10] = {&t.m00, &t.m01, &t.m02, &t.m03, &t.m10, &t.m11, &t.m12, &t.m20, &t.m21, &t.m30};
+    for (int i = 0; i < 10; i++)
+        for (int k = 0; k < 3; k++) c.m[i][k] = (*src[i])[k];
+}
+V3 trispline_position(const Trispline &s, double t, double u) {                 // trispline.rs:162-167
+    return s.m30 * (t * t * t) + s.m20 * (t * t) + s.m10 * t + s.m00 + s.m21 * (t * t * u) + s.m11 * (t * u) +
+           s.m01 * u + s.m12 * (t * u * u) + s.m02 * (u * u) + s.m03 * (u * u * u);
+}
+V3 trispline_ddt(const Trispline &s, double t, double u) {                      // trispline.rs:168-172
+    return s.m30 * (3.0 * t * t) + s.m20 * (2.0 * t) + s.m10 + s.m21 * (2.0 * t * u) + s.m11 * u + s.m12 * (u * u);
+}
+V3 trispline_ddu(const Trispline &s, double t, double u) {                      // trispline.rs:173-177
+    return s.m21 * (t * t) + s.m11 * (t) + s.m01 + s.m12 * (t * 2.0 * u) + s.m02 * (2.0 * u) + s.m03 * (3.0 * u * u);
+}
+V3 trispline_normal(const Trispline &s, double t, double u) {                   // trispline.rs:178-180
+    return g_normalize(cross(trispline_ddt(s, t, u), trispline_ddu(s, t, u)));
+}
+struct HermiteSpline {
+    V3 p0, p1, d0, d1;
+};
+struct Spline {
+    V3 a, b, c, d;
+};
+void hermite_normalize_speed(HermiteSpline &h) {                                // trispline.rs:144-150
+    double distance = g_length(h.p0 - h.p1);
+    h.d0 = g_normalize(h.d0) * distance;
+    h.d1 = g_normalize(h.d1) * distance;
+}
+Spline spline_from_hermite(const HermiteSpline &h) {                            // trispline.rs:126-134
+    Spline s;
+    s.a = smul(2.0, h.p0) - smul(2.0, h.p1) + smul(1.0, h.d0) + smul(1.0, h.d1);
+    s.b = smul(-3.0, h.p0) + smul(3.0, h.p1) - smul(2.0, h.d0) - smul(1.0, h.d1);
+    s.c = h.d0;
+    s.d = h.p0;
+    return s;
+}
+// NormalHermiteTrispline -> HermiteTrispline -> SplineTrispline -> Trispline (trispline.rs:68-124).
+// in: p0,p1,p2,p01,p12,p20,n0,n1,n2,control
+Trispline trispline_from_normal_hermite(const V3 in[10]) {
+    V3 p0 = in[0], p1 = in[1], p2 = in[2], p01 = in[3], p12 = in[4], p20 = in[5];
+    V3 n0 = in[6], n1 = in[7], n2 = in[8], control = in[9];
+    V3 d01 = cross(p2 - p01, n0);
+    V3 d10 = cross(p2 - p01, n1);
+    V3 d02 = -cross(p1 - p20, n0);
+    V3 d20 = -cross(p1 - p20, n2);
+    V3 d12 = -cross(p0 - p12, n1);
+    V3 d21 = -cross(p0 - p12, n2);
+    HermiteSpline h01{p0, p1, d01, d10}, h02{p0, p2, d02, d20}, h21{p2, p1, d21, d12};
+    hermite_normalize_speed(h01);
+    hermite_normalize_speed(h02);
+    hermite_normalize_speed(h21);
+    Spline f = spline_from_hermite(h01), g = spline_from_hermite(h02), h = spline_from_hermite(h21);
+    V3 s1 = f.c - g.c - smul(2.0, g.b) - smul(3.0, g.a) - h.c;                   // trispline.rs:105
+    V3 s3 = f.a - g.a - h.a;                                                     // trispline.rs:107
+    Trispline t;
+    t.m11 = control;
+    t.m12 = -t.m11 - s1;
+    t.m21 = s3 + t.m12;
+    t.m00 = f.d;
+    t.m01 = g.c;
+    t.m02 = g.b;
+    t.m03 = g.a;
+    t.m10 = f.c;
+    t.m20 = f.b;
+    t.m30 = f.a;
+    return t;
+}
+
 Bounds node_bounds(const rtg_bvh_node &n) {
     return Bounds{mk(n.lo[0], n.lo[1], n.lo[2]), mk(n.hi[0], n.hi[1], n.hi[2])};
 }
@@ -514,7 +601,46 @@ TriVerts leaf_tri(const rtg_tri &t) {
     for (int i = 0; i < 3; i++) tv.p[i] = mk(t.p[i][0], t.p[i][1], t.p[i][2]);
     return tv;
 }
+// Ray / patch intersection: this build's definition (the reference has none), see rtg_patch_set in rtg.h.
+bool patch_leaf_raycast(const orc_bvh &b, uint32_t leaf, const Ray &ray, RaycastPoint &out) {
+    TriVerts tv = leaf_tri(b.leaves[leaf]);
+    TrianglePoint tp;
+    if (!triangle_raycast(tv.p, ray, false, tp)) return false;
+    const rtg_patch_leaf &li = b.leaf_info[leaf];
+    Trispline sp = trispline_from_c(b.patches[li.patch]);
+    double t = ((0.0 + tp.bary[0] * li.tu[0][0]) + tp.bary[1] * li.tu[1][0]) + tp.bary[2] * li.tu[2][0];
+    double u = ((0.0 + tp.bary[0] * li.tu[0][1]) + tp.bary[1] * li.tu[1][1]) + tp.bary[2] * li.tu[2][1];
+    double tau = tp.time;
+    V3 c = -ray.dir;
+    for (uint32_t it = 0; it < b.newton_steps; it++) {
+        V3 a = trispline_ddt(sp, t, u), bb = trispline_ddu(sp, t, u);
+        V3 r = ray.pos(tau) - trispline_position(sp, t, u);
+        V3 bc = cross(bb, c);
+        double det = dot(a, bc);
+        double dt = dot(r, bc) / det;
+        double du = dot(a, cross(r, c)) / det;
+        double dtau = dot(a, cross(bb, r)) / det;
+        t = t + dt;
+        u = u + du;
+        tau = tau + dtau;
+    }
+    V3 f = trispline_position(sp, t, u) - ray.pos(tau);
+    double tol2 = 1e-20 * (dot(sp.m10, sp.m10) + dot(sp.m01, sp.m01));
+    if (!(t >= 0.0 && u >= 0.0 && t + u <= 1.0 && tau >= 0.0 && dot(f, f) <= tol2)) return false;
+    V3 n = trispline_normal(sp, t, u);
+    out.time = tau;
+    out.position = ray.pos(tau);
+    out.inter_normal = n;
+    out.geo_normal = n;
+    out.manifold = Manifold{{0, 0}, 0};
+    out.mp[0] = t;
+    out.mp[1] = u;
+    out.material = Material{mk(QNAN, QNAN, QNAN), false, 0.0, 0.0};
+    out.material_slot = 0;
+    return true;
+}
 bool leaf_raycast(const orc_bvh &b, uint32_t leaf, const Ray &ray, bool manifold, RaycastPoint &out) {
+    if (!b.patches.empty()) return patch_leaf_raycast(b, leaf, ray, out);
     TriVerts tv = leaf_tri(b.leaves[leaf]);
     if (b.normals.empty()) return triverts_raycast(tv, nullptr, ray, manifold, out);
     V3 n[3];
@@ -722,6 +848,7 @@ bool any_object_raycast(const orc_scene::Obj &o, uint32_t index, const Ray &ray,
         out.material = o.material;
         out.material_slot = index * 2;
         return true;
+    case RTG_PATCHES:
     case RTG_MESH:                                                              // mesh_object.rs:22-27
         if (!o.mesh || !bvh_raycast(*o.mesh, ray, out, ctr)) return false;
         out.material = o.material;
@@ -1108,6 +1235,55 @@ int orc_bvh_raycast_brute(const orc_bvh *b, const double ray6[6], rtg_hit *out) 
     out->leaf = h.has ? h.point.manifold.array[0] : RTG_NONE;
     out->t = h.has ? h.point.time : INF;
     return h.has ? 1 : 0;
+}
+
+void orc_trispline_from_normal_hermite(const double in30[30], rtg_trispline *out) {
+    V3 in[10];
+    for (int i = 0; i < 10; i++) in[i] = mk(in30[i * 3], in30[i * 3 + 1], in30[i * 3 + 2]);
+    trispline_to_c(trispline_from_normal_hermite(in), *out);
+}
+/* out12 = position, ddt, ddu, normal */
+void orc_trispline_eval(const rtg_trispline *sp, double t, double u, double out12[12]) {
+    Trispline s = trispline_from_c(*sp);
+    V3 v[4] = {trispline_position(s, t, u), trispline_ddt(s, t, u), trispline_ddu(s, t, u), trispline_normal(s, t, u)};
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 3; k++) out12[i * 3 + k] = v[i][k];
+}
+/* k*k facets per patch, in the order: for i, for j: "up" facet, then (when it exists) "down" facet */
+void orc_patches_tessellate(const rtg_trispline *patches, uint64_t n, uint32_t k, rtg_tri *out_tris,
+                            rtg_patch_leaf *out_info) {
+    uint64_t w = 0;
+    for (uint64_t p = 0; p < n; p++) {
+        Trispline s = trispline_from_c(patches[p]);
+        auto emit = [&](const double tu[3][2]) {
+            for (int c = 0; c < 3; c++) {
+                V3 q = trispline_position(s, tu[c][0], tu[c][1]);
+                for (int a = 0; a < 3; a++) out_tris[w].p[c][a] = q[a];
+                out_info[w].tu[c][0] = tu[c][0];
+                out_info[w].tu[c][1] = tu[c][1];
+            }
+            out_info[w].patch = (uint32_t)p;
+            out_info[w]._pad = 0;
+            w++;
+        };
+        for (uint32_t i = 0; i < k; i++)
+            for (uint32_t j = 0; j + i < k; j++) {
+                double t0 = (double)i / (double)k, t1 = (double)(i + 1) / (double)k;
+                double u0 = (double)j / (double)k, u1 = (double)(j + 1) / (double)k;
+                const double up[3][2] = {{t0, u0}, {t1, u0}, {t0, u1}};
+                emit(up);
+                if (j + i + 1 < k) {
+                    const double down[3][2] = {{t1, u0}, {t1, u1}, {t0, u1}};
+                    emit(down);
+                }
+            }
+    }
+}
+/* leaf_info in leaf order (as rtg_patch_set) */
+void orc_bvh_set_patches(orc_bvh *b, const rtg_patch_set *ps) {
+    b->patches.assign(ps->patches, ps->patches + ps->n_patches);
+    b->leaf_info.assign(ps->leaf_info, ps->leaf_info + b->leaves.size());
+    b->newton_steps = ps->newton_steps;
 }
 
 orc_scene *orc_scene_create(const rtg_scene_desc *desc) {

@@ -89,6 +89,17 @@ int orc_bvh_raycast(const orc_bvh *b, const double ray6[6], rtg_hit *out, rtg_ra
 /* every leaf tested in index order with the holder's strict-< rule (no boxes) */
 int orc_bvh_raycast_brute(const orc_bvh *b, const double ray6[6], rtg_hit *out);
 
+/* ---- trispline patches (src/trispline.rs) -------------------------------- */
+/* in30: p0,p1,p2,p01,p12,p20,n0,n1,n2,control (NormalHermiteTrispline, trispline.rs:24-36) */
+void orc_trispline_from_normal_hermite(const double in30[30], rtg_trispline *out);
+/* out12 = position, ddt, ddu, normal at (t,u) */
+void orc_trispline_eval(const rtg_trispline *sp, double t, double u, double out12[12]);
+/* k*k flat facets per patch with their corner parameters */
+void orc_patches_tessellate(const rtg_trispline *patches, uint64_t n, uint32_t k, rtg_tri *out_tris,
+                            rtg_patch_leaf *out_info);
+/* turns a facet BVH into a patch mesh; ps->leaf_info is in leaf order */
+void orc_bvh_set_patches(orc_bvh *b, const rtg_patch_set *ps);
+
 /* ---- scene / renderer -------------------------------------------------- */
 orc_scene *orc_scene_create(const rtg_scene_desc *desc);
 void orc_scene_destroy(orc_scene *s);

@@ -43,6 +43,8 @@ struct rtg_mesh {
     rtg_ctx *ctx = nullptr;
     DevMesh dev{};
     void *d_nodes = nullptr, *d_tnodes = nullptr, *d_tris = nullptr, *d_normals = nullptr;
+    void *d_patches = nullptr, *d_leaf_info = nullptr;
+    bool is_patches = false;
     double bounds[6] = {0, 0, 0, 0, 0, 0};
     uint64_t n_leaves = 0;
 };
@@ -510,7 +512,40 @@ void rtg_mesh_destroy(rtg_mesh *m) {
     if (m->d_tnodes) (void)hipFree(m->d_tnodes);
     if (m->d_tris) (void)hipFree(m->d_tris);
     if (m->d_normals) (void)hipFree(m->d_normals);
+    if (m->d_patches) (void)hipFree(m->d_patches);
+    if (m->d_leaf_info) (void)hipFree(m->d_leaf_info);
     delete m;
+}
+
+int rtg_mesh_create_patches(rtg_ctx *ctx, const rtg_bvh *bvh, const rtg_patch_set *ps, rtg_mesh **out) {
+    if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
+    if (!bvh || !ps || !out) return fail(ctx, RTG_E_INVALID, "rtg_mesh_create_patches: null argument");
+    *out = nullptr;
+    if (ps->n_patches == 0 || !ps->patches) return fail(ctx, RTG_E_INVALID, "rtg_mesh_create_patches: no patches");
+    if (bvh->n_leaves && !ps->leaf_info) return fail(ctx, RTG_E_INVALID, "rtg_mesh_create_patches: leaf_info is null");
+    if (ps->n_patches >= 0x7FFFFFFFull) return fail(ctx, RTG_E_LIMIT, "rtg_mesh_create_patches: too many patches");
+    if (ps->newton_steps > 64) return fail(ctx, RTG_E_LIMIT, "rtg_mesh_create_patches: newton_steps exceeds 64");
+    for (uint64_t i = 0; i < bvh->n_leaves; i++)
+        if (ps->leaf_info[i].patch >= ps->n_patches)
+            return fail(ctx, RTG_E_INVALID, "rtg_mesh_create_patches: leaf %llu names patch %u of %llu",
+                        (unsigned long long)i, ps->leaf_info[i].patch, (unsigned long long)ps->n_patches);
+    rtg_bvh plain = *bvh;
+    plain.vertex_normals = nullptr;
+    rtg_mesh *m = nullptr;
+    int rc = rtg_mesh_create(ctx, &plain, &m);
+    if (rc != RTG_OK) return rc;
+    rc = upload(ctx, ps->patches, (size_t)ps->n_patches * sizeof(rtg_trispline), &m->d_patches);
+    if (rc == RTG_OK) rc = upload(ctx, ps->leaf_info, (size_t)bvh->n_leaves * sizeof(rtg_patch_leaf), &m->d_leaf_info);
+    if (rc != RTG_OK) {
+        rtg_mesh_destroy(m);
+        return rc;
+    }
+    m->is_patches = true;
+    m->dev.patches = (const rtg_trispline *)m->d_patches;
+    m->dev.leaf_info = (const rtg_patch_leaf *)m->d_leaf_info;
+    m->dev.newton_steps = ps->newton_steps;
+    *out = m;
+    return RTG_OK;
 }
 
 int rtg_mesh_bounds(const rtg_mesh *mesh, double out[6]) {
@@ -557,13 +592,15 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
         case RTG_PLANE:
             break;
         case RTG_MESH:
+        case RTG_PATCHES:
             if (!o.mesh) return fail(ctx, RTG_E_INVALID, "object %u: mesh handle is null", i);
             if (o.mesh->ctx != ctx) return fail(ctx, RTG_E_INVALID, "object %u: mesh belongs to another context", i);
+            if ((o.kind == RTG_PATCHES) != o.mesh->is_patches)
+                return fail(ctx, RTG_E_INVALID, "object %u: kind %d does not match the mesh handle (%s)", i, o.kind,
+                            o.mesh->is_patches ? "patch set" : "triangle mesh");
             d.mesh = o.mesh->dev;
             if (o.mesh->dev.depth > max_depth) max_depth = o.mesh->dev.depth;
             break;
-        case RTG_PATCHES:
-            return fail(ctx, RTG_E_UNSUPPORTED, "object %u: trispline patch objects are not built yet", i);
         default:
             return fail(ctx, RTG_E_INVALID, "object %u: unknown kind %d", i, o.kind);
         }
@@ -583,6 +620,9 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
     s->dev.overflow = nullptr;
     s->dev.overflow_levels = 0;
     s->dev.overflow_stride = 1;
+    s->dev.has_patches = 0;
+    for (uint32_t i = 0; i < desc->n_objects; i++)
+        if (desc->objects[i].kind == RTG_PATCHES) s->dev.has_patches = 1;
     *out = s;
     return RTG_OK;
 }

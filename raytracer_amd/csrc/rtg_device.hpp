@@ -47,6 +47,10 @@ struct DevMesh {
     uint32_t root;
     uint32_t depth;
     uint32_t fast_div_ok;        // every box coordinate is 0 or has 2^-600 <= |c| <= 2^400
+    const rtg_trispline *patches;     // non-null: leaves are facets of trispline patches
+    const rtg_patch_leaf *leaf_info;  // per leaf: patch index and corner parameters
+    uint32_t newton_steps;
+    uint32_t pad;
 };
 
 struct DevMaterial {
@@ -77,6 +81,7 @@ struct DevScene {
     uint32_t *overflow;          // global stack overflow slab (may be null when unused)
     uint32_t overflow_levels;    // levels available per thread in the slab
     uint32_t overflow_stride;    // threads the slab was sized for
+    uint32_t has_patches;        // some object is a trispline patch set: launch the PATCH kernel variants
 };
 
 // ------------------------------------------------------------------- math --
@@ -304,6 +309,98 @@ __device__ __forceinline__ bool plane_hit_time(V3 p, V3 tan1, V3 tan2, const Ray
     return !(t < 0.0);
 }
 
+// -------------------------------------------------------- trispline patches --
+// Patch evaluation (trispline.rs:161-181, glam::DVec3 arithmetic: products and
+// sums strictly left to right) and this library's ray/patch intersection (see
+// rtg_patch_set in rtg.h).
+struct Patch {
+    V3 m00, m01, m02, m03, m10, m11, m12, m20, m21, m30;
+};
+__device__ __forceinline__ Patch load_patch(const rtg_trispline *p) {
+    const double *d = &p->m[0][0];
+    Patch s;
+    s.m00 = ld3(d);
+    s.m01 = ld3(d + 3);
+    s.m02 = ld3(d + 6);
+    s.m03 = ld3(d + 9);
+    s.m10 = ld3(d + 12);
+    s.m11 = ld3(d + 15);
+    s.m12 = ld3(d + 18);
+    s.m20 = ld3(d + 21);
+    s.m21 = ld3(d + 24);
+    s.m30 = ld3(d + 27);
+    return s;
+}
+__device__ __forceinline__ V3 patch_position(const Patch &s, double t, double u) {
+    return s.m30 * (t * t * t) + s.m20 * (t * t) + s.m10 * t + s.m00 + s.m21 * (t * t * u) + s.m11 * (t * u) +
+           s.m01 * u + s.m12 * (t * u * u) + s.m02 * (u * u) + s.m03 * (u * u * u);
+}
+__device__ __forceinline__ V3 patch_ddt(const Patch &s, double t, double u) {
+    return s.m30 * (3.0 * t * t) + s.m20 * (2.0 * t) + s.m10 + s.m21 * (2.0 * t * u) + s.m11 * u + s.m12 * (u * u);
+}
+__device__ __forceinline__ V3 patch_ddu(const Patch &s, double t, double u) {
+    return s.m21 * (t * t) + s.m11 * t + s.m01 + s.m12 * (t * 2.0 * u) + s.m02 * (2.0 * u) + s.m03 * (3.0 * u * u);
+}
+// glam normalize: v * (1 / length), dot without the leading 0.0
+__device__ __forceinline__ V3 glam_normalize(V3 a) {
+    double l2 = (a.x * a.x + a.y * a.y) + a.z * a.z;
+    return a * (1.0 / __builtin_sqrt(l2));
+}
+struct PatchHit {
+    double tau, t, u;
+    V3 normal;
+};
+// Full Triangle::raycast (manifold == false) including the barycentrics.
+__device__ __forceinline__ bool tri_hit_full(V3 v0, V3 v1, V3 v2, const Ray &r, double &t_out, V3 &bary) {
+    V3 e01 = v1 - v0, e12 = v2 - v1, e20 = v0 - v2;
+    V3 nt = cross(e01, e12);
+    double denom = dot(nt, nt);
+    bool ok = !(dot(nt, r.d) > 0.0);
+    double t = dot(v0 - r.o, nt) / dot(r.d, nt);
+    ok = ok && !(t < 0.0);
+    V3 q = ray_pos(r, t);
+    double c0 = dot(cross(e01, q - v0), nt) / denom;
+    double c1 = dot(cross(e12, q - v1), nt) / denom;
+    double c2 = dot(cross(e20, q - v2), nt) / denom;
+    ok = ok && !(c0 < 0.0) && !(c1 < 0.0) && !(c2 < 0.0);
+    t_out = t;
+    bary = mk(c1, c2, c0);
+    return ok;
+}
+template <bool WANT_NORMAL>
+__device__ __forceinline__ bool patch_leaf_hit(const rtg_trispline *patches, const rtg_patch_leaf *info,
+                                               uint32_t newton_steps, V3 v0, V3 v1, V3 v2, const Ray &r,
+                                               PatchHit &out) {
+    double tf;
+    V3 bary;
+    if (!tri_hit_full(v0, v1, v2, r, tf, bary)) return false;
+    Patch sp = load_patch(patches + info->patch);
+    double t = ((0.0 + bary.x * info->tu[0][0]) + bary.y * info->tu[1][0]) + bary.z * info->tu[2][0];
+    double u = ((0.0 + bary.x * info->tu[0][1]) + bary.y * info->tu[1][1]) + bary.z * info->tu[2][1];
+    double tau = tf;
+    V3 c = neg(r.d);
+    for (uint32_t it = 0; it < newton_steps; it++) {
+        V3 a = patch_ddt(sp, t, u), b = patch_ddu(sp, t, u);
+        V3 res = ray_pos(r, tau) - patch_position(sp, t, u);
+        V3 bc = cross(b, c);
+        double det = dot(a, bc);
+        double dt = dot(res, bc) / det;
+        double du = dot(a, cross(res, c)) / det;
+        double dtau = dot(a, cross(b, res)) / det;
+        t = t + dt;
+        u = u + du;
+        tau = tau + dtau;
+    }
+    V3 f = patch_position(sp, t, u) - ray_pos(r, tau);
+    double tol2 = 1e-20 * (dot(sp.m10, sp.m10) + dot(sp.m01, sp.m01));
+    if (!(t >= 0.0 && u >= 0.0 && t + u <= 1.0 && tau >= 0.0 && dot(f, f) <= tol2)) return false;
+    out.tau = tau;
+    out.t = t;
+    out.u = u;
+    if (WANT_NORMAL) out.normal = glam_normalize(cross(patch_ddt(sp, t, u), patch_ddu(sp, t, u)));
+    return true;
+}
+
 // ---------------------------------------------------------------- holder --
 // RaycastPointHolder (render/object.rs:29-31,60-79) reduced to what decides the
 // result: whether a point is held, its time and its leaf.
@@ -348,14 +445,21 @@ __device__ __forceinline__ void load_tri(const DevTri *p, V3 &v0, V3 &v1, V3 &v2
     v2 = mk(d.x, d.y, e);
 }
 
-template <bool COUNT>
+template <bool COUNT, bool PATCH>
 __device__ __forceinline__ void test_leaves(const DevMesh &m, uint32_t begin, uint32_t count,
                                             const Ray &r, Holder &h, Counter &ctr) {
     for (uint32_t i = 0; i < count; i++) {
         V3 v0, v1, v2;
         load_tri(m.tris + begin + i, v0, v1, v2);
         double t;
-        bool some = tri_hit_time(v0, v1, v2, r, t);
+        bool some;
+        if (PATCH && m.patches) {
+            PatchHit ph;
+            some = patch_leaf_hit<false>(m.patches, m.leaf_info + begin + i, m.newton_steps, v0, v1, v2, r, ph);
+            t = ph.tau;
+        } else {
+            some = tri_hit_time(v0, v1, v2, r, t);
+        }
         holder_add(h, some, t, begin + i);
         if (COUNT) ctr.tris++;
     }
@@ -406,7 +510,7 @@ struct ShortStack {
     }
 };
 
-template <bool COUNT>
+template <bool COUNT, bool PATCH>
 __device__ __forceinline__ void traverse_stack(const DevMesh &m, const Ray &r, Holder &h, Counter &ctr,
                                                uint32_t *lds_col, uint32_t *glob_col, uint32_t gstride) {
     ShortStack st;
@@ -428,7 +532,7 @@ __device__ __forceinline__ void traverse_stack(const DevMesh &m, const Ray &r, H
         else
             st.s0 = cur + 1;
         if (box_hit(lo, hi, r, holder_bound(h))) {
-            test_leaves<COUNT>(m, tail.z, tail.w, r, h, ctr);
+            test_leaves<COUNT, PATCH>(m, tail.z, tail.w, r, h, ctr);
             if (tail.y & 0x7FFFFFFFu) st.push(tail.x);
         }
     }
@@ -438,7 +542,7 @@ __device__ __forceinline__ void traverse_stack(const DevMesh &m, const Ray &r, H
 // is followed by the next array element (its first child, or whatever follows
 // a childless node); a node that fails jumps over its subtree through the skip
 // link.  Same visit order as the recursion, no stack.
-template <bool COUNT>
+template <bool COUNT, bool PATCH>
 __device__ __forceinline__ void traverse_threaded(const DevMesh &m, const Ray &r, Holder &h, Counter &ctr) {
     uint32_t cur = 0;
     const uint32_t end = m.n_nodes;
@@ -448,7 +552,7 @@ __device__ __forceinline__ void traverse_threaded(const DevMesh &m, const Ray &r
         load_node(m.tnodes + cur, lo, hi, tail);
         if (COUNT) ctr.nodes++;
         if (box_hit(lo, hi, r, holder_bound(h))) {
-            test_leaves<COUNT>(m, tail.z, tail.w, r, h, ctr);
+            test_leaves<COUNT, PATCH>(m, tail.z, tail.w, r, h, ctr);
             cur = cur + 1;
         } else {
             cur = tail.x;
@@ -480,7 +584,7 @@ __device__ __forceinline__ Ray inner_ray(const DevObject &o, const Ray &outer) {
 // SceneObject::raycast(ray, None) (render/scene_object.rs:19-36) reduced to the
 // winner's identity: every object in order, `.min()` keeps the first minimum
 // under real_cmp, where NaN sorts below every number (math/scalar.rs:46-60).
-template <bool COUNT>
+template <bool COUNT, bool PATCH>
 __device__ __forceinline__ SceneHit scene_closest(const DevScene &s, const Ray &ray, const TraceCtx &tc,
                                                   Counter &ctr) {
     SceneHit best;
@@ -498,16 +602,16 @@ __device__ __forceinline__ SceneHit scene_closest(const DevScene &s, const Ray &
             some = sphere_hit_time(ld3(o.sphere_center), o.sphere_radius, in, t);
         } else if (o.kind == RTG_PLANE) {
             some = plane_hit_time(ld3(o.plane_position), ld3(o.plane_tan1), ld3(o.plane_tan2), in, t);
-        } else if (o.kind == RTG_MESH) {
+        } else if (o.kind == RTG_MESH || o.kind == RTG_PATCHES) {
             if (o.mesh.n_nodes != 0) {
                 Holder h;
                 h.has = false;
                 h.t = kInf;
                 h.leaf = RTG_NONE;
                 if (s.traversal == 1)
-                    traverse_threaded<COUNT>(o.mesh, in, h, ctr);
+                    traverse_threaded<COUNT, PATCH>(o.mesh, in, h, ctr);
                 else
-                    traverse_stack<COUNT>(o.mesh, in, h, ctr, tc.lds_col, tc.glob_col, tc.gstride);
+                    traverse_stack<COUNT, PATCH>(o.mesh, in, h, ctr, tc.lds_col, tc.glob_col, tc.gstride);
                 some = h.has;
                 t = h.t;
                 leaf = h.leaf;
@@ -530,6 +634,7 @@ __device__ __forceinline__ SceneHit scene_closest(const DevScene &s, const Ray &
 // the reference would have produced it on the way up: primitive point in the
 // object's space, then TransformObject's position / normal fix-up
 // (render/transform_object.rs:22-27) and SceneObject's manifold push.
+template <bool PATCH>
 __device__ __forceinline__ void scene_point(const DevScene &s, const Ray &ray, const SceneHit &hit, rtg_point &out) {
     out.time = hit.have ? hit.t : kInf;
     out.manifold[0] = 0;
@@ -576,9 +681,20 @@ __device__ __forceinline__ void scene_point(const DevScene &s, const Ray &ray, c
     } else {
         V3 v0, v1, v2;
         load_tri(o.mesh.tris + hit.leaf, v0, v1, v2);
-        TriPoint tp = tri_point(v0, v1, v2, in);
+        TriPoint tp;
+        if (PATCH && o.mesh.patches) {
+            PatchHit ph;
+            ph.t = 0.0;
+            ph.u = 0.0;
+            ph.normal = mk(0.0, 0.0, 0.0);
+            patch_leaf_hit<true>(o.mesh.patches, o.mesh.leaf_info + hit.leaf, o.mesh.newton_steps, v0, v1, v2, in, ph);
+            tp.n = ph.normal;
+            tp.bary = mk(ph.t, ph.u, 0.0);
+        } else {
+            tp = tri_point(v0, v1, v2, in);
+        }
         ng = tp.n;
-        if (o.mesh.normals) {
+        if (o.mesh.normals && !(PATCH && o.mesh.patches)) {
             const double *nn = o.mesh.normals + (size_t)hit.leaf * 9;
             V3 n0 = ld3(nn), n1 = ld3(nn + 3), n2 = ld3(nn + 6);
             ni = normalize((n0 * tp.bary.x + n1 * tp.bary.y) + n2 * tp.bary.z);
@@ -628,7 +744,7 @@ __device__ __forceinline__ Ray primary_ray(const rtg_view &v, uint32_t x, uint32
 // --------------------------------------------------------------- shading --
 // compute_direct_irrad (render/renderer.rs:184-205): one closest-hit shadow
 // query per light, Lambert term over 4*pi*dis^2.
-template <bool COUNT>
+template <bool COUNT, bool PATCH>
 __device__ __forceinline__ V3 direct_irrad(const DevScene &s, const rtg_light *lights, uint32_t n_lights,
                                            V3 position, V3 inter_normal, const TraceCtx &tc, Counter &ctr) {
     V3 lighting = mk(1.0, 1.0, 1.0) * 0.0;
@@ -642,7 +758,7 @@ __device__ __forceinline__ V3 direct_irrad(const DevScene &s, const rtg_light *l
         double d = dot(dir, inter_normal);
         if (d < 0.0) continue;
         Ray ray = new_bounce(position, dir);
-        SceneHit occ = scene_closest<COUNT>(s, ray, tc, ctr);
+        SceneHit occ = scene_closest<COUNT, PATCH>(s, ray, tc, ctr);
         if (occ.have && occ.t < dis) continue;
         lighting = lighting + (color * d) / (4.0 * kPi * dis2);
     }

@@ -37,7 +37,7 @@ __device__ __forceinline__ void store_hit(rtg_hit *out, const SceneHit &h) {
     *reinterpret_cast<uint4 *>(out) = v;
 }
 
-template <bool COUNT, bool POINTS>
+template <bool COUNT, bool POINTS, bool PATCH>
 __global__ __launch_bounds__(kBlock) void k_render_primary(DevScene s, rtg_view view, uint32_t width,
                                                             uint32_t height, rtg_rect tile, uint32_t tiles_x,
                                                             uint32_t n_tiles, rtg_hit *out_hits,
@@ -55,16 +55,16 @@ __global__ __launch_bounds__(kBlock) void k_render_primary(DevScene s, rtg_view 
     Counter ctr;
     ctr.nodes = 0;
     ctr.tris = 0;
-    SceneHit h = scene_closest<COUNT>(s, ray, tc, ctr);
+    SceneHit h = scene_closest<COUNT, PATCH>(s, ray, tc, ctr);
     if (out_hits) store_hit(out_hits + idx, h);
-    if (POINTS) scene_point(s, ray, h, out_points[idx]);
+    if (POINTS) scene_point<PATCH>(s, ray, h, out_points[idx]);
     if (COUNT) {
         out_counters[idx].nodes_visited = ctr.nodes;
         out_counters[idx].tris_tested = ctr.tris;
     }
 }
 
-template <bool COUNT, bool POINTS>
+template <bool COUNT, bool POINTS, bool PATCH>
 __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const double *__restrict__ rays6, uint64_t n,
                                                    rtg_hit *out_hits, rtg_point *out_points,
                                                    rtg_ray_counters *out_counters) {
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const double *__re
     Counter ctr;
     ctr.nodes = 0;
     ctr.tris = 0;
-    SceneHit h = scene_closest<COUNT>(s, ray, tc, ctr);
+    SceneHit h = scene_closest<COUNT, PATCH>(s, ray, tc, ctr);
     if (out_hits) store_hit(out_hits + gid, h);
-    if (POINTS) scene_point(s, ray, h, out_points[gid]);
+    if (POINTS) scene_point<PATCH>(s, ray, h, out_points[gid]);
     if (COUNT) {
         out_counters[gid].nodes_visited = ctr.nodes;
         out_counters[gid].tris_tested = ctr.tris;
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const double *__re
 }
 
 // compute_direct_irrad x diffuse for already-built points (renderer.rs:184-205,270-277).
+template <bool PATCH>
 __global__ __launch_bounds__(kBlock) void k_shade_direct(DevScene s, const rtg_light *__restrict__ lights,
                                                           uint32_t n_lights, const rtg_point *__restrict__ points,
                                                           uint64_t n, double *rgb_out, uint8_t *rgba8_out) {
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_direct(DevScene s, const rtg_l
     V3 total = mk(0.0, 0.0, 0.0);
     if (pt.manifold_len != 0) {
         Counter ctr;
-        V3 irrad = (mk(0.0, 0.0, 0.0) + direct_irrad<false>(s, lights, n_lights, ld3(pt.position),
+        V3 irrad = (mk(0.0, 0.0, 0.0) + direct_irrad<false, PATCH>(s, lights, n_lights, ld3(pt.position),
                                                              ld3(pt.inter_normal), tc, ctr)) +
                    mk(0.0, 0.0, 0.0);
         const DevMaterial &m = material_of_slot(s, pt.material_slot);
@@ -179,6 +180,7 @@ struct Pending {
     uint32_t depth;
 };
 
+template <bool PATCH>
 __global__ __launch_bounds__(kBlock) void k_render_frame(DevScene s, rtg_view view,
                                                           const rtg_light *__restrict__ lights, uint32_t n_lights,
                                                           uint32_t width, uint32_t height, rtg_rect tile,
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void k_render_frame(DevScene s, rtg_view vi
     bool first = true;
     V3 total = mk(0.0, 0.0, 0.0);
     while (live) {
-        SceneHit h = scene_closest<false>(s, ray, tc, ctr);
+        SceneHit h = scene_closest<false, PATCH>(s, ray, tc, ctr);
         if (first) {
             if (out_hits) store_hit(out_hits + idx, h);
             first = false;
@@ -212,9 +214,9 @@ __global__ __launch_bounds__(kBlock) void k_render_frame(DevScene s, rtg_view vi
         bool cont = false;
         if (h.have) {
             rtg_point pt;
-            scene_point(s, ray, h, pt);
+            scene_point<PATCH>(s, ray, h, pt);
             const DevMaterial &m = material_of_slot(s, pt.material_slot);
-            V3 irrad = (mk(0.0, 0.0, 0.0) + direct_irrad<false>(s, lights, n_lights, ld3(pt.position),
+            V3 irrad = (mk(0.0, 0.0, 0.0) + direct_irrad<false, PATCH>(s, lights, n_lights, ld3(pt.position),
                                                                  ld3(pt.inter_normal), tc, ctr)) +
                        mk(0.0, 0.0, 0.0);
             V3 dm = mk(irrad.x * m.diffuse[0], irrad.y * m.diffuse[1], irrad.z * m.diffuse[2]);
@@ -279,18 +281,19 @@ hipError_t launch_render_primary(hipStream_t stream, const DevScene &s, const rt
     if (n_tiles == 0) return hipSuccess;
     dim3 grid(n_tiles), block(kBlock);
     bool count = out_counters != nullptr, points = out_points != nullptr;
-    if (count && points)
-        hipLaunchKernelGGL((k_render_primary<true, true>), grid, block, 0, stream, s, view, width, height, tile,
-                           tiles_x, n_tiles, out_hits, out_points, out_counters);
-    else if (count)
-        hipLaunchKernelGGL((k_render_primary<true, false>), grid, block, 0, stream, s, view, width, height, tile,
-                           tiles_x, n_tiles, out_hits, out_points, out_counters);
-    else if (points)
-        hipLaunchKernelGGL((k_render_primary<false, true>), grid, block, 0, stream, s, view, width, height, tile,
-                           tiles_x, n_tiles, out_hits, out_points, out_counters);
-    else
-        hipLaunchKernelGGL((k_render_primary<false, false>), grid, block, 0, stream, s, view, width, height, tile,
-                           tiles_x, n_tiles, out_hits, out_points, out_counters);
+#define RTG_L(C, P, X) hipLaunchKernelGGL((k_render_primary<C, P, X>), grid, block, 0, stream, s, view, width, height, tile, tiles_x, n_tiles, out_hits, out_points, out_counters)
+    if (s.has_patches) {
+        if (count && points) RTG_L(true, true, true);
+        else if (count) RTG_L(true, false, true);
+        else if (points) RTG_L(false, true, true);
+        else RTG_L(false, false, true);
+    } else {
+        if (count && points) RTG_L(true, true, false);
+        else if (count) RTG_L(true, false, false);
+        else if (points) RTG_L(false, true, false);
+        else RTG_L(false, false, false);
+    }
+#undef RTG_L
     return hipGetLastError();
 }
 
@@ -299,18 +302,19 @@ hipError_t launch_trace(hipStream_t stream, const DevScene &s, const double *ray
     if (n == 0) return hipSuccess;
     dim3 grid((uint32_t)((n + kBlock - 1) / kBlock)), block(kBlock);
     bool count = out_counters != nullptr, points = out_points != nullptr;
-    if (count && points)
-        hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, stream, s, rays6, n, out_hits, out_points,
-                           out_counters);
-    else if (count)
-        hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, stream, s, rays6, n, out_hits, out_points,
-                           out_counters);
-    else if (points)
-        hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, stream, s, rays6, n, out_hits, out_points,
-                           out_counters);
-    else
-        hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, stream, s, rays6, n, out_hits, out_points,
-                           out_counters);
+#define RTG_L(C, P, X) hipLaunchKernelGGL((k_trace<C, P, X>), grid, block, 0, stream, s, rays6, n, out_hits, out_points, out_counters)
+    if (s.has_patches) {
+        if (count && points) RTG_L(true, true, true);
+        else if (count) RTG_L(true, false, true);
+        else if (points) RTG_L(false, true, true);
+        else RTG_L(false, false, true);
+    } else {
+        if (count && points) RTG_L(true, true, false);
+        else if (count) RTG_L(true, false, false);
+        else if (points) RTG_L(false, true, false);
+        else RTG_L(false, false, false);
+    }
+#undef RTG_L
     return hipGetLastError();
 }
 
@@ -318,7 +322,10 @@ hipError_t launch_shade_direct(hipStream_t stream, const DevScene &s, const rtg_
                                const rtg_point *points, uint64_t n, double *rgb_out, uint8_t *rgba8_out) {
     if (n == 0) return hipSuccess;
     dim3 grid((uint32_t)((n + kBlock - 1) / kBlock)), block(kBlock);
-    hipLaunchKernelGGL(k_shade_direct, grid, block, 0, stream, s, lights, n_lights, points, n, rgb_out, rgba8_out);
+    if (s.has_patches)
+        hipLaunchKernelGGL(k_shade_direct<true>, grid, block, 0, stream, s, lights, n_lights, points, n, rgb_out, rgba8_out);
+    else
+        hipLaunchKernelGGL(k_shade_direct<false>, grid, block, 0, stream, s, lights, n_lights, points, n, rgb_out, rgba8_out);
     return hipGetLastError();
 }
 
@@ -329,8 +336,12 @@ hipError_t launch_render_frame(hipStream_t stream, const DevScene &s, const rtg_
     uint32_t n_tiles = tiles_x * tiles_y;
     if (n_tiles == 0) return hipSuccess;
     dim3 grid(n_tiles), block(kBlock);
-    hipLaunchKernelGGL(k_render_frame, grid, block, 0, stream, s, view, lights, n_lights, width, height, tile,
-                       tiles_x, n_tiles, max_depth, out_rgb, out_rgba8, out_hits);
+    if (s.has_patches)
+        hipLaunchKernelGGL(k_render_frame<true>, grid, block, 0, stream, s, view, lights, n_lights, width, height, tile,
+                           tiles_x, n_tiles, max_depth, out_rgb, out_rgba8, out_hits);
+    else
+        hipLaunchKernelGGL(k_render_frame<false>, grid, block, 0, stream, s, view, lights, n_lights, width, height, tile,
+                           tiles_x, n_tiles, max_depth, out_rgb, out_rgba8, out_hits);
     return hipGetLastError();
 }
 

@@ -234,7 +234,7 @@ struct PhasedParams {
 };
 
 // STATS builds add per-wave step/lane tallies into work_counters[8*kCounterStride ...] (diagnostics only).
-template <class Source, bool COUNT, bool POINTS, bool STATS = false>
+template <class Source, bool COUNT, bool POINTS, bool PATCH, bool STATS = false>
 __global__ __launch_bounds__(kBlock, 4) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
                                                           uint32_t *work_counters, PhasedParams prm,
                                                           rtg_hit *out_hits, rtg_point *out_points,
@@ -267,6 +267,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_trace_phased(DevScene s, Source s
     uint32_t obj_i = 0, cur = 0, end = 0, leaf_cur = 0, leaf_end = 0;
     GNodePtr nodes = nullptr;
     GTriPtr tris = nullptr;
+    const rtg_trispline *patches = nullptr;
+    const rtg_patch_leaf *leaf_info = nullptr;
+    uint32_t newton_steps = 0;
     Counter ctr;
     ctr.nodes = 0;
     ctr.tris = 0;
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_trace_phased(DevScene s, Source s
                         v.w = (uint32_t)(tb >> 32);
                         *reinterpret_cast<uint4 *>(out_hits + out_index) = v;
                     }
-                    if (POINTS) scene_point(s, ray, sh, out_points[out_index]);
+                    if (POINTS) scene_point<PATCH>(s, ray, sh, out_points[out_index]);
                     if (COUNT) {
                         out_counters[out_index].nodes_visited = ctr.nodes;
                         out_counters[out_index].tris_tested = ctr.tris;
@@ -354,9 +357,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_trace_phased(DevScene s, Source s
                     some = sphere_hit_time(ld3(o.sphere_center), o.sphere_radius, in, t);
                 } else if (o.kind == RTG_PLANE) {
                     some = plane_hit_time(ld3(o.plane_position), ld3(o.plane_tan1), ld3(o.plane_tan2), in, t);
-                } else if (o.kind == RTG_MESH && o.mesh.n_nodes != 0) {
+                } else if ((o.kind == RTG_MESH || o.kind == RTG_PATCHES) && o.mesh.n_nodes != 0) {
                     nodes = (GNodePtr)o.mesh.tnodes;
                     tris = (GTriPtr)o.mesh.tris;
+                    patches = o.mesh.patches;
+                    leaf_info = o.mesh.leaf_info;
+                    newton_steps = o.mesh.newton_steps;
                     end = o.mesh.n_nodes;
                     cur = 0;
                     h.has = false;
@@ -421,7 +427,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_trace_phased(DevScene s, Source s
                 V3 v0, v1, v2;
                 load_tri_g(tris + leaf_cur, v0, v1, v2);
                 double t;
-                bool some = tri_hit_time_signs(v0, v1, v2, in, t);
+                bool some;
+                if (PATCH && patches) {
+                    PatchHit ph;
+                    some = patch_leaf_hit<false>(patches, leaf_info + leaf_cur, newton_steps, v0, v1, v2, in, ph);
+                    t = ph.tau;
+                } else {
+                    some = tri_hit_time_signs(v0, v1, v2, in, t);
+                }
                 holder_add(h, some, t, leaf_cur);
                 if (COUNT) ctr.tris++;
                 leaf_cur++;
@@ -530,21 +543,23 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     PhasedParams prm{tune.tri_min, tune.obj_min, tune.idle_min};
     dim3 g(grid), b(kBlock);
     bool count = out_counters != nullptr, points = out_points != nullptr;
-    if (tune.stats && !count && !points)
-        hipLaunchKernelGGL((k_trace_phased<Source, false, false, true>), g, b, 0, stream, s, src, n_items, work_counters,
-                           prm, out_hits, out_points, out_counters);
-    else if (count && points)
-        hipLaunchKernelGGL((k_trace_phased<Source, true, true>), g, b, 0, stream, s, src, n_items, work_counters, prm,
-                           out_hits, out_points, out_counters);
-    else if (count)
-        hipLaunchKernelGGL((k_trace_phased<Source, true, false>), g, b, 0, stream, s, src, n_items, work_counters, prm,
-                           out_hits, out_points, out_counters);
-    else if (points)
-        hipLaunchKernelGGL((k_trace_phased<Source, false, true>), g, b, 0, stream, s, src, n_items, work_counters, prm,
-                           out_hits, out_points, out_counters);
-    else
-        hipLaunchKernelGGL((k_trace_phased<Source, false, false>), g, b, 0, stream, s, src, n_items, work_counters, prm,
-                           out_hits, out_points, out_counters);
+#define RTG_L(C, P, X, S)                                                                                          \
+    hipLaunchKernelGGL((k_trace_phased<Source, C, P, X, S>), g, b, 0, stream, s, src, n_items, work_counters, prm, \
+                       out_hits, out_points, out_counters)
+    if (s.has_patches) {
+        if (count && points) RTG_L(true, true, true, false);
+        else if (count) RTG_L(true, false, true, false);
+        else if (points) RTG_L(false, true, true, false);
+        else RTG_L(false, false, true, false);
+    } else if (tune.stats && !count && !points) {
+        RTG_L(false, false, false, true);
+    } else {
+        if (count && points) RTG_L(true, true, false, false);
+        else if (count) RTG_L(true, false, false, false);
+        else if (points) RTG_L(false, true, false, false);
+        else RTG_L(false, false, false, false);
+    }
+#undef RTG_L
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 
 #include "rt_bvh.hpp"
 #include "rt_mesh.hpp"
+#include "rt_patch.hpp"
 #include "rt_scene.hpp"
 
 struct rth_bvh {
@@ -38,6 +39,30 @@ void rth_sort_rays(const double lo_hi[6], const double *rays6, uint64_t n, uint3
     std::stable_sort(perm, perm + n, [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
     if (sorted)
         for (uint64_t i = 0; i < n; i++) std::memcpy(sorted + i * 6, rays6 + (size_t)perm[i] * 6, 6 * sizeof(double));
+}
+
+void rth_trispline_from_normal_hermite(const double in30[30], rtg_trispline *out) {
+    rt::NormalHermiteTrispline nh;
+    rt::D3 *f[10] = {&nh.p0, &nh.p1, &nh.p2, &nh.p01, &nh.p12, &nh.p20, &nh.n0, &nh.n1, &nh.n2, &nh.control};
+    for (int i = 0; i < 10; i++) *f[i] = rt::D3{in30[i * 3], in30[i * 3 + 1], in30[i * 3 + 2]};
+    *out = rt::trispline_from(nh);
+}
+void rth_trispline_eval(const rtg_trispline *sp, double t, double u, double out12[12]) {
+    rt::D3 v[4] = {rt::trispline_position(*sp, t, u), rt::trispline_ddt(*sp, t, u), rt::trispline_ddu(*sp, t, u),
+                   rt::trispline_normal(*sp, t, u)};
+    for (int i = 0; i < 4; i++) {
+        out12[i * 3] = v[i].x;
+        out12[i * 3 + 1] = v[i].y;
+        out12[i * 3 + 2] = v[i].z;
+    }
+}
+void rth_patches_tessellate(const rtg_trispline *patches, uint64_t n, uint32_t k, rtg_tri *out_tris,
+                            rtg_patch_leaf *out_info) {
+    rt::tessellate(patches, n, k, out_tris, out_info);
+}
+void rth_patch_terrain(uint32_t nx, uint32_t ny, uint64_t seed, double scale, rtg_trispline *out) {
+    std::vector<rtg_trispline> p = rt::patch_terrain(nx, ny, seed, scale);
+    std::memcpy(out, p.data(), p.size() * sizeof(rtg_trispline));
 }
 
 void rth_transform_build(double scale, const double translate[3], rtg_transform *out) {

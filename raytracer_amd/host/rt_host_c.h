@@ -22,6 +22,14 @@ void rth_bench_mesh_rays(const double lo_hi[6], uint64_t n, uint64_t seed, doubl
 /* Stable sort of rays by (direction octant, Morton code of origin); perm[i] = source index of sorted ray i. */
 void rth_sort_rays(const double lo_hi[6], const double *rays6, uint64_t n, uint32_t *perm, double *sorted_rays6);
 
+/* trispline patches (src/trispline.rs): in30 = p0,p1,p2,p01,p12,p20,n0,n1,n2,control */
+void rth_trispline_from_normal_hermite(const double in30[30], rtg_trispline *out);
+/* out12 = position, ddt, ddu, normal */
+void rth_trispline_eval(const rtg_trispline *sp, double t, double u, double out12[12]);
+void rth_patches_tessellate(const rtg_trispline *patches, uint64_t n, uint32_t k, rtg_tri *out_tris, rtg_patch_leaf *out_info);
+/* 2*nx*ny patches over the heightfield terrain */
+void rth_patch_terrain(uint32_t nx, uint32_t ny, uint64_t seed, double scale, rtg_trispline *out);
+
 /* TransformBuilder::new().scale(s).translate(x,y,z).build() (src/geo/transform.rs:33-49) */
 void rth_transform_build(double scale, const double translate[3], rtg_transform *out);
 /* SceneBuilder{time} (src/lib.rs:42-121): objects[2] = sphere, plane; lights[2]; view. */

@@ -38,6 +38,11 @@ class Bvh(C.Structure):
                 ("vertex_normals", C.c_void_p), ("root", C.c_uint32)]
 
 
+class PatchSet(C.Structure):
+    _fields_ = [("patches", C.c_void_p), ("n_patches", C.c_uint64), ("leaf_info", C.c_void_p),
+                ("newton_steps", C.c_uint32)]
+
+
 class Material(C.Structure):
     _fields_ = [("diffuse", C.c_double * 3), ("n1", C.c_double), ("n2", C.c_double), ("has_dielectric", C.c_int32),
                 ("_pad", C.c_int32)]
@@ -77,6 +82,7 @@ POINT_DTYPE = np.dtype([("time", "<f8"), ("position", "<f8", 3), ("inter_normal"
                         ("geo_normal", "<f8", 3), ("manifold_point", "<f8", 2), ("manifold", "<u4", 2),
                         ("manifold_len", "<u4"), ("material_slot", "<u4")])
 COUNTER_DTYPE = np.dtype([("nodes_visited", "<u4"), ("tris_tested", "<u4")])
+PATCH_LEAF_DTYPE = np.dtype([("tu", "<f8", (3, 2)), ("patch", "<u4"), ("_pad", "<u4")])
 LIGHT_DTYPE = np.dtype([("position", "<f8", 3), ("color", "<f8", 3)])
 assert NODE_DTYPE.itemsize == 64 and HIT_DTYPE.itemsize == 16 and POINT_DTYPE.itemsize == 112
 assert C.sizeof(BvhNode) == 64 and C.sizeof(Transform) == 328 and C.sizeof(Material) == 48
@@ -106,6 +112,7 @@ _sig(lib.rtg_ctx_debug_stats, C.c_int, _vp, C.POINTER(C.c_uint32))
 _sig(lib.rtg_selftest_division, C.c_int, _vp, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64))
 _sig(lib.rtg_transform_from_forward, C.c_int, C.POINTER(C.c_double), C.POINTER(Transform))
 _sig(lib.rtg_mesh_create, C.c_int, _vp, C.POINTER(Bvh), C.POINTER(_vp))
+_sig(lib.rtg_mesh_create_patches, C.c_int, _vp, C.POINTER(Bvh), C.POINTER(PatchSet), C.POINTER(_vp))
 _sig(lib.rtg_mesh_destroy, None, _vp)
 _sig(lib.rtg_mesh_bounds, C.c_int, _vp, C.POINTER(C.c_double))
 _sig(lib.rtg_scene_create, C.c_int, _vp, C.POINTER(SceneDesc), C.POINTER(_vp))
@@ -124,6 +131,10 @@ _sig(host.rth_bvh_depth, C.c_uint32, _vp)
 _sig(host.rth_heightfield, None, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, _vp)
 _sig(host.rth_bench_mesh_rays, None, C.POINTER(C.c_double), C.c_uint64, C.c_uint64, _vp)
 _sig(host.rth_sort_rays, None, C.POINTER(C.c_double), _vp, C.c_uint64, _vp, _vp)
+_sig(host.rth_trispline_from_normal_hermite, None, _vp, _vp)
+_sig(host.rth_trispline_eval, None, _vp, C.c_double, C.c_double, _vp)
+_sig(host.rth_patches_tessellate, None, _vp, C.c_uint64, C.c_uint32, _vp, _vp)
+_sig(host.rth_patch_terrain, None, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, _vp)
 _sig(host.rth_transform_build, None, C.c_double, C.POINTER(C.c_double), C.POINTER(Transform))
 _sig(host.rth_scene_builder, None, C.c_uint64, C.POINTER(Object), C.POINTER(Light), C.POINTER(View))
 _sig(host.rth_render_scene_builder, C.c_int, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp)
@@ -153,6 +164,60 @@ def heightfield(nx, ny, seed=1, scale=1.0):
     tris = np.empty((2 * nx * ny, 3, 3), dtype=np.float64)
     host.rth_heightfield(nx, ny, seed, float(scale), _ptr(tris))
     return tris
+
+
+def trispline_from_normal_hermite(nh):
+    """NormalHermiteTrispline (10 x 3: p0,p1,p2,p01,p12,p20,n0,n1,n2,control) -> Trispline coefficients (10 x 3)."""
+    nh = np.ascontiguousarray(nh, dtype=np.float64).reshape(10, 3)
+    out = np.empty((10, 3), dtype=np.float64)
+    host.rth_trispline_from_normal_hermite(_ptr(nh), _ptr(out))
+    return out
+
+
+def trispline_eval(patch, t, u):
+    """(position, ddt, ddu, normal) of one patch at (t, u)."""
+    patch = np.ascontiguousarray(patch, dtype=np.float64).reshape(10, 3)
+    out = np.empty((4, 3), dtype=np.float64)
+    host.rth_trispline_eval(_ptr(patch), float(t), float(u), _ptr(out))
+    return out
+
+
+def patches_tessellate(patches, k):
+    """k*k flat facets per patch: ((n*k*k, 3, 3) triangles, PATCH_LEAF_DTYPE info)."""
+    patches = np.ascontiguousarray(patches, dtype=np.float64).reshape(-1, 10, 3)
+    n = patches.shape[0] * k * k
+    tris = np.empty((n, 3, 3), dtype=np.float64)
+    info = np.zeros(n, dtype=PATCH_LEAF_DTYPE)
+    host.rth_patches_tessellate(_ptr(patches), patches.shape[0], k, _ptr(tris), _ptr(info))
+    return tris, info
+
+
+def patch_terrain(nx, ny, seed=1, scale=1.0):
+    """2*nx*ny trispline patches over the heightfield terrain: (n, 10, 3)."""
+    out = np.empty((2 * nx * ny, 10, 3), dtype=np.float64)
+    host.rth_patch_terrain(nx, ny, seed, float(scale), _ptr(out))
+    return out
+
+
+class HostPatchMesh:
+    """Patches + their facet BVH (host-built): what rtg_mesh_create_patches consumes."""
+
+    def __init__(self, patches, k=4, newton_steps=5, threads=0):
+        self.patches = np.ascontiguousarray(patches, dtype=np.float64).reshape(-1, 10, 3)
+        tris, info = patches_tessellate(self.patches, k)
+        self.bvh = HostBvh(tris, threads=threads)
+        self.leaf_info = np.ascontiguousarray(info[self.bvh.leaf_source()])   # facet order -> leaf order
+        self.newton_steps = newton_steps
+        self.k = k
+
+    def patch_set(self):
+        ps = PatchSet()
+        ps.patches = self.patches.ctypes.data
+        ps.n_patches = self.patches.shape[0]
+        ps.leaf_info = self.leaf_info.ctypes.data
+        ps.newton_steps = self.newton_steps
+        ps._keep = self
+        return ps
 
 
 def bench_mesh_rays(lo_hi, n, seed=10212233):
@@ -266,7 +331,10 @@ class HostBvh:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the library globals may already be gone
+            pass
 
 
 def flat_bvh(nodes, leaves, root, vertex_normals=None):
@@ -340,16 +408,24 @@ class Context:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the library globals may already be gone
+            pass
 
 
 class Mesh:
     _h = None
 
     def __init__(self, ctx, bvh):
-        view = bvh.view if isinstance(bvh, HostBvh) else bvh
         h = _vp()
-        ctx._check(lib.rtg_mesh_create(ctx._h, C.byref(view), C.byref(h)))
+        if isinstance(bvh, HostPatchMesh):
+            ps = bvh.patch_set()
+            ctx._check(lib.rtg_mesh_create_patches(ctx._h, C.byref(bvh.bvh.view), C.byref(ps), C.byref(h)))
+        else:
+            view = bvh.view if isinstance(bvh, HostBvh) else bvh
+            ctx._check(lib.rtg_mesh_create(ctx._h, C.byref(view), C.byref(h)))
+        self._keep = bvh
         self._h = h
         self.ctx = ctx
 
@@ -368,7 +444,10 @@ class Mesh:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the library globals may already be gone
+            pass
 
 
 def sphere_object(center, radius, mat, xform=None):
@@ -400,6 +479,12 @@ def mesh_object(mesh, mat, xform=None):
     o.material = mat
     o.mesh = mesh.handle if isinstance(mesh, Mesh) else mesh
     o._keep = mesh
+    return o
+
+
+def patch_object(mesh, mat, xform=None):
+    o = mesh_object(mesh, mat, xform)
+    o.kind = PATCHES
     return o
 
 
@@ -475,7 +560,10 @@ class Scene:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the library globals may already be gone
+            pass
 
 
 def make_view(orig=(0.0, 0.0, 1.0), fov=(np.pi * 0.5, np.pi * 0.5)):

@@ -60,6 +60,10 @@ _sig(lib.orc_bvh_leaf_source, C.POINTER(C.c_uint32), _vp)
 _sig(lib.orc_bvh_depth, C.c_uint32, _vp)
 _sig(lib.orc_bvh_raycast, C.c_int, _vp, _dp, _vp, _vp)
 _sig(lib.orc_bvh_raycast_brute, C.c_int, _vp, _dp, _vp)
+_sig(lib.orc_trispline_from_normal_hermite, None, _vp, _vp)
+_sig(lib.orc_trispline_eval, None, _vp, C.c_double, C.c_double, _vp)
+_sig(lib.orc_patches_tessellate, None, _vp, C.c_uint64, C.c_uint32, _vp, _vp)
+_sig(lib.orc_bvh_set_patches, None, _vp, C.POINTER(rtg.PatchSet))
 _sig(lib.orc_scene_create, _vp, C.POINTER(rtg.SceneDesc))
 _sig(lib.orc_scene_destroy, None, _vp)
 _sig(lib.orc_render_primary, C.c_int, _vp, C.POINTER(rtg.View), C.c_uint32, C.c_uint32, rtg.Rect, _vp, _vp, _vp, C.c_int)
@@ -133,6 +137,29 @@ def dielectric(inc, signed_norm, n1, n2):
     return {"reflectance": o[0], "reflect": o[1:4], "has_refract": o[4] != 0.0, "refract": o[5:8]}
 
 
+def trispline_from_normal_hermite(nh):
+    nh = np.ascontiguousarray(nh, dtype=np.float64).reshape(10, 3)
+    out = np.empty((10, 3), dtype=np.float64)
+    lib.orc_trispline_from_normal_hermite(nh.ctypes.data, out.ctypes.data)
+    return out
+
+
+def trispline_eval(patch, t, u):
+    patch = np.ascontiguousarray(patch, dtype=np.float64).reshape(10, 3)
+    out = np.empty((4, 3), dtype=np.float64)
+    lib.orc_trispline_eval(patch.ctypes.data, float(t), float(u), out.ctypes.data)
+    return out
+
+
+def patches_tessellate(patches, k):
+    patches = np.ascontiguousarray(patches, dtype=np.float64).reshape(-1, 10, 3)
+    n = patches.shape[0] * k * k
+    tris = np.empty((n, 3, 3), dtype=np.float64)
+    info = np.zeros(n, dtype=rtg.PATCH_LEAF_DTYPE)
+    lib.orc_patches_tessellate(patches.ctypes.data, patches.shape[0], k, tris.ctypes.data, info.ctypes.data)
+    return tris, info
+
+
 class OracleBvh:
     _h = None
 
@@ -187,6 +214,10 @@ class OracleBvh:
             buf = (C.c_char * (self.n_leaves * 72)).from_address(p)
             vn = np.frombuffer(buf, dtype=np.float64).copy()
         return rtg.flat_bvh(self.nodes(), self.leaves(), self.root, vn)
+
+    def set_patches(self, patch_set):
+        self._patch_keep = patch_set
+        lib.orc_bvh_set_patches(self._h, C.byref(patch_set))
 
     def raycast(self, ray, counters=False):
         hit = np.zeros(1, dtype=rtg.HIT_DTYPE)

@@ -44,8 +44,13 @@ class Pair:
         for i, o in enumerate(objects):
             g = rtg.copy_object(o)
             if i in bvhs:
-                view = bvhs[i].view if isinstance(bvhs[i], rtg.HostBvh) else bvhs[i]
+                if isinstance(bvhs[i], rtg.HostPatchMesh):
+                    view = bvhs[i].bvh.view
+                else:
+                    view = bvhs[i].view if isinstance(bvhs[i], rtg.HostBvh) else bvhs[i]
                 self.obvhs[i] = orc.OracleBvh(flat=view)
+                if isinstance(bvhs[i], rtg.HostPatchMesh):
+                    self.obvhs[i].set_patches(bvhs[i].patch_set())
                 oobjs.append(orc.oracle_object(o, self.obvhs[i]))
                 if ctx is not None:
                     self.meshes[i] = ctx.mesh(bvhs[i])
@@ -82,6 +87,13 @@ def float_bits_differ(a, b):
 def hit_mismatches(a, b):
     bad = (a["object"] != b["object"]) | (a["leaf"] != b["leaf"]) | float_bits_differ(a["t"], b["t"])
     return np.flatnonzero(bad)
+
+
+def patch_scene_objects(xform, with_default=True, time=0, diffuse=(0.7, 0.8, 0.6)):
+    """Like mesh_scene_objects, with a trispline patch object instead of the triangle mesh."""
+    objs, lights, view = mesh_scene_objects(xform, with_default, time, diffuse)
+    objs[-1].kind = rtg.PATCHES
+    return objs, lights, view
 
 
 def same_hits(a, b):
