@@ -210,7 +210,7 @@ int rtg_ctx_synchronize(rtg_ctx *ctx);
  *   "traversal" 0 = one ray per lane, short stack (VGPR window + LDS spill + global overflow)
  *               1 = one ray per lane, threaded pre-order tree (skip links, no stack)
  *               2 = persistent phase-scheduled waves over the threaded tree
- *   "tri_min" / "obj_min" / "idle_min"  scheduling thresholds of traversal 2 (lanes)
+ *   "tri_min" / "obj_min"               scheduling thresholds of traversal 2 (lanes)
  *   "max_blocks"                        persistent grid size of traversal 2
  *   "stats" 2 = tally steps per phase in traversal 2 (diagnostics), 1 = off */
 int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value);

@@ -390,10 +390,6 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) {
         ctx->tune.obj_min = (uint32_t)(value > 64 ? 64 : value);
         return RTG_OK;
     }
-    if (std::strcmp(key, "idle_min") == 0) {
-        ctx->tune.idle_min = (uint32_t)(value > 64 ? 64 : value);
-        return RTG_OK;
-    }
     if (std::strcmp(key, "max_blocks") == 0) {
         ctx->tune.max_blocks = (uint32_t)value;
         return RTG_OK;

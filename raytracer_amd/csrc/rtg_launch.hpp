@@ -19,9 +19,8 @@ hipError_t launch_render_frame(hipStream_t stream, const DevScene &s, const rtg_
 
 // Persistent phase-scheduled kernels (rtg_phased.hip).
 struct PhasedTuning {
-    uint32_t tri_min = 8;
-    uint32_t obj_min = 4;
-    uint32_t idle_min = 12;
+    uint32_t tri_min = 12;
+    uint32_t obj_min = 8;
     uint32_t max_blocks = 1024;
     uint32_t stats = 0;          // diagnostics build: tally steps and lanes per phase
 };

@@ -13,8 +13,9 @@
 //     at once; a lane with a pending triangle does not advance, so every ray
 //     still sees exactly the reference's visit order and best-time pruning
 //     (tree/bvh.rs:118-133);
-//   * finished lanes go IDLE and are refilled with new rays once `idle_min`
-//     lanes are idle, from 64-ray chunks handed out by per-XCD work counters
+//   * a lane whose ray has seen every object waits in OBJ until `obj_min` lanes
+//     are there; one OBJ step then stores the finished hits, hands out new rays
+//     (64-ray chunks from per-XCD work counters) and enters the next object
 //     (blocks b and b+8 share an XCD and its L2, so each XCD first drains its
 //     own contiguous eighth of the frame and only then helps the others).
 //
@@ -33,6 +34,9 @@
 
 namespace rtg {
 
+#ifndef RTG_PHASED_WAVES
+#define RTG_PHASED_WAVES 4
+#endif
 enum : uint32_t { PH_IDLE = 0, PH_OBJ = 1, PH_NODE = 2, PH_TRI = 3 };
 
 // ---- ray sources ------------------------------------------------------------------
@@ -230,12 +234,11 @@ struct WorkQueue {
 struct PhasedParams {
     uint32_t tri_min;     // run a TRI step once this many lanes wait for one
     uint32_t obj_min;     // same for the between-objects step
-    uint32_t idle_min;    // refill once this many lanes are idle
 };
 
 // STATS builds add per-wave step/lane tallies into work_counters[8*kCounterStride ...] (diagnostics only).
 template <class Source, bool COUNT, bool POINTS, bool PATCH, bool STATS = false>
-__global__ __launch_bounds__(kBlock, 4) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
+__global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
                                                           uint32_t *work_counters, PhasedParams prm,
                                                           rtg_hit *out_hits, rtg_point *out_points,
                                                           rtg_ray_counters *out_counters) {
@@ -246,12 +249,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_trace_phased(DevScene s, Source s
     wq.per_range = (wq.total_chunks + 7) >> 3;
     wq.range = blockIdx.x & 7u;
     wq.tried = 0;
-    bool exhausted = false;
+    bool exhausted = false;       // wave-uniform: every work range has been drained
     uint64_t chunk_base = 0;      // wave-uniform
     uint32_t chunk_left = 0;      // wave-uniform
 
     // per-lane state
-    uint32_t phase = PH_IDLE;
+    uint32_t phase = PH_OBJ;      // every lane starts by asking for a ray
+    bool has_ray = false;
     uint64_t out_index = 0;
     Ray ray{};                    // outer ray
     Ray in{};                     // ray in the current object's space
@@ -276,12 +280,44 @@ __global__ __launch_bounds__(kBlock, 4) void k_trace_phased(DevScene s, Source s
 
     for (;;) {
         if (STATS) st_iter++;
-        uint64_t m_idle = __ballot(phase == PH_IDLE);
-        uint32_t n_idle = (uint32_t)__popcll(m_idle);
-        // ---- refill ---------------------------------------------------------------
-        if (!exhausted && (n_idle >= prm.idle_min || n_idle == 64u)) {
-            if (STATS) st_refill++;
-            while (m_idle != 0) {
+        uint64_t m_node = __ballot(phase == PH_NODE);
+        uint64_t m_tri = __ballot(phase == PH_TRI);
+        uint64_t m_obj = __ballot(phase == PH_OBJ);
+        if ((m_node | m_tri | m_obj) == 0) break;   // every lane is done and no chunk is left
+
+        // ---- between objects: finish the ray, fetch the next one, enter the next object -------
+        if (m_obj != 0 && ((uint32_t)__popcll(m_obj) >= prm.obj_min || (m_node | m_tri) == 0)) {
+            if (STATS) {
+                st_obj++;
+                st_obj_l += (uint32_t)__popcll(m_obj);
+            }
+            // (1) a ray that has seen every object reports its closest hit
+            if (phase == PH_OBJ && has_ray && obj_i >= s.n_objects) {
+                SceneHit sh;
+                sh.have = best_have;
+                sh.t = best_t;
+                sh.object = best_obj;
+                sh.leaf = best_leaf;
+                if (out_hits) {
+                    uint64_t tb = __double_as_longlong(sh.have ? sh.t : kInf);
+                    uint4 v;
+                    v.x = sh.have ? sh.object : RTG_NONE;
+                    v.y = sh.have ? sh.leaf : RTG_NONE;
+                    v.z = (uint32_t)tb;
+                    v.w = (uint32_t)(tb >> 32);
+                    *reinterpret_cast<uint4 *>(out_hits + out_index) = v;
+                }
+                if (POINTS) scene_point<PATCH>(s, ray, sh, out_points[out_index]);
+                if (COUNT) {
+                    out_counters[out_index].nodes_visited = ctr.nodes;
+                    out_counters[out_index].tris_tested = ctr.tris;
+                }
+                has_ray = false;
+            }
+            // (2) lanes without a ray take the next items of the wave's chunk
+            uint64_t m_need = __ballot(phase == PH_OBJ && !has_ray);
+            while (m_need != 0 && !exhausted) {
+                if (STATS) st_refill++;
                 if (chunk_left == 0) {
                     uint32_t chunk;
                     if (!wq.grab(chunk)) {
@@ -291,12 +327,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_trace_phased(DevScene s, Source s
                     chunk_base = (uint64_t)chunk << 6;
                     chunk_left = 64;
                 }
-                uint32_t rank = lane_rank(m_idle);
-                uint32_t n_take = n_idle < chunk_left ? n_idle : chunk_left;
-                if (phase == PH_IDLE && rank < n_take) {
+                uint32_t n_need = (uint32_t)__popcll(m_need);
+                uint32_t rank = lane_rank(m_need);
+                uint32_t n_take = n_need < chunk_left ? n_need : chunk_left;
+                if (phase == PH_OBJ && !has_ray && rank < n_take) {
                     uint64_t item = chunk_base + (64u - chunk_left) + rank;
                     if (src.make(item, ray, out_index)) {
-                        phase = PH_OBJ;
+                        has_ray = true;
                         obj_i = 0;
                         best_have = false;
                         best_t = kInf;
@@ -307,48 +344,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_trace_phased(DevScene s, Source s
                     }
                 }
                 chunk_left -= n_take;
-                m_idle = __ballot(phase == PH_IDLE);
-                n_idle = (uint32_t)__popcll(m_idle);
+                m_need = __ballot(phase == PH_OBJ && !has_ray);
             }
-        }
-        uint64_t m_node = __ballot(phase == PH_NODE);
-        uint64_t m_tri = __ballot(phase == PH_TRI);
-        uint64_t m_obj = __ballot(phase == PH_OBJ);
-        if ((m_node | m_tri | m_obj) == 0) {
-            if (exhausted) break;
-            continue;   // everything idle but chunks remain: refill on the next turn
-        }
-
-        // ---- between objects: next object, or finish the ray -----------------------
-        if (m_obj != 0 && ((uint32_t)__popcll(m_obj) >= prm.obj_min || (m_node | m_tri) == 0)) {
-            if (STATS) {
-                st_obj++;
-                st_obj_l += (uint32_t)__popcll(m_obj);
-            }
-            while (phase == PH_OBJ) {
-                if (obj_i >= s.n_objects) {
-                    SceneHit sh;
-                    sh.have = best_have;
-                    sh.t = best_t;
-                    sh.object = best_obj;
-                    sh.leaf = best_leaf;
-                    if (out_hits) {
-                        uint64_t tb = __double_as_longlong(sh.have ? sh.t : kInf);
-                        uint4 v;
-                        v.x = sh.have ? sh.object : RTG_NONE;
-                        v.y = sh.have ? sh.leaf : RTG_NONE;
-                        v.z = (uint32_t)tb;
-                        v.w = (uint32_t)(tb >> 32);
-                        *reinterpret_cast<uint4 *>(out_hits + out_index) = v;
-                    }
-                    if (POINTS) scene_point<PATCH>(s, ray, sh, out_points[out_index]);
-                    if (COUNT) {
-                        out_counters[out_index].nodes_visited = ctr.nodes;
-                        out_counters[out_index].tris_tested = ctr.tris;
-                    }
-                    phase = PH_IDLE;
-                    break;
-                }
+            if (exhausted && phase == PH_OBJ && !has_ray) phase = PH_IDLE;   // nothing left for this lane
+            // (3) walk the object list up to the next mesh (spheres and planes are done in place)
+            while (phase == PH_OBJ && has_ray && obj_i < s.n_objects) {
                 const DevObject &o = s.objects[obj_i];
                 in = inner_ray(o, ray);
                 bool some = false;
@@ -540,7 +540,7 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     uint64_t want = (chunks + 3) / 4;
     uint32_t grid = (uint32_t)(want < tune.max_blocks ? want : tune.max_blocks);
     if (grid == 0) grid = 1;
-    PhasedParams prm{tune.tri_min, tune.obj_min, tune.idle_min};
+    PhasedParams prm{tune.tri_min, tune.obj_min};
     dim3 g(grid), b(kBlock);
     bool count = out_counters != nullptr, points = out_points != nullptr;
 #define RTG_L(C, P, X, S)                                                                                          \

@@ -15,7 +15,8 @@ SPHERE, MESH, PLANE, PATCHES = 0, 1, 2, 3
 
 
 def _load(name):
-    path = os.path.join(_HERE, name)
+    # RTG_LIBRTG_PATH: A/B a differently built kernel library without touching the tree (diagnostics only)
+    path = os.environ.get("RTG_LIBRTG_PATH") if name == "librtg.so" and os.environ.get("RTG_LIBRTG_PATH") else os.path.join(_HERE, name)
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -236,7 +236,10 @@ class OracleBvh:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown
+            pass
 
 
 class OracleScene:
@@ -299,7 +302,10 @@ class OracleScene:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown
+            pass
 
 
 def oracle_object(obj, oracle_bvh=None):
