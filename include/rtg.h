@@ -212,6 +212,7 @@ int rtg_ctx_synchronize(rtg_ctx *ctx);
  *               2 = persistent phase-scheduled waves over the threaded tree
  *   "tri_min" / "obj_min"               scheduling thresholds of traversal 2 (lanes)
  *   "max_blocks"                        persistent grid size of traversal 2
+ *   "pretest" 2 = on (default), 1 = off: single-precision box pre-test of traversal 2
  *   "stats" 2 = tally steps per phase in traversal 2 (diagnostics), 1 = off */
 int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value);
 /* Diagnostics for traversal 2 after a launch with "stats" on: loop iterations,

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <new>
 #include <string>
@@ -43,7 +44,7 @@ struct rtg_mesh {
     rtg_ctx *ctx = nullptr;
     DevMesh dev{};
     void *d_nodes = nullptr, *d_tnodes = nullptr, *d_tris = nullptr, *d_normals = nullptr;
-    void *d_patches = nullptr, *d_leaf_info = nullptr;
+    void *d_patches = nullptr, *d_leaf_info = nullptr, *d_hot = nullptr;
     bool is_patches = false;
     double bounds[6] = {0, 0, 0, 0, 0, 0};
     uint64_t n_leaves = 0;
@@ -394,6 +395,10 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) {
         ctx->tune.max_blocks = (uint32_t)value;
         return RTG_OK;
     }
+    if (std::strcmp(key, "pretest") == 0) {
+        ctx->tune.pretest = value > 1 ? 1u : 0u;   // 2 = on, 1 = off
+        return RTG_OK;
+    }
     if (std::strcmp(key, "stats") == 0) {
         ctx->tune.stats = value > 1 ? 1u : 0u;   // 2 = on, 1 = off (0 is rejected above as out of range)
         return RTG_OK;
@@ -497,6 +502,35 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) {
                 if (!(c == 0.0 || (a >= 0x1p-600 && a <= 0x1p400))) fast_ok = 0;
             }
     m->dev.fast_div_ok = fast_ok;
+    // single-precision companion nodes for the pre-test
+    {
+        std::vector<HotNode> hot(thr_nodes.size());
+        uint32_t f32_ok = 1;
+        double cmax = 0.0;
+        for (size_t i = 0; i < thr_nodes.size(); i++) {
+            const DevNode &n = thr_nodes[i];
+            for (int k = 0; k < 3; k++) {
+                hot[i].lo[k] = (float)n.lo[k];
+                hot[i].hi[k] = (float)n.hi[k];
+                for (double c : {n.lo[k], n.hi[k]}) {
+                    double a = std::fabs(c);
+                    if (!(c == 0.0 || (a >= 0x1p-40 && a <= 0x1p40))) f32_ok = 0;
+                    if (a > cmax) cmax = a;
+                }
+            }
+            hot[i].skip = n.link;
+            hot[i].leaf_ref = n.leaf_count == 0 ? 0xFFFFFFFFu : (n.leaf_count == 1 ? n.leaf_begin : 0x80000000u);
+        }
+        rc = upload(ctx, hot.data(), hot.size() * sizeof(HotNode), &m->d_hot);
+        if (rc != RTG_OK) {
+            rtg_mesh_destroy(m);
+            return rc;
+        }
+        m->dev.hot = (const HotNode *)m->d_hot;
+        m->dev.f32_ok = f32_ok && std::isfinite(cmax) ? 1u : 0u;
+        // rounded up so the kernel's error bound never under-estimates
+        m->dev.coord_max = std::nextafter((float)cmax, std::numeric_limits<float>::infinity());
+    }
     *out = m;
     return RTG_OK;
 }
@@ -508,6 +542,7 @@ void rtg_mesh_destroy(rtg_mesh *m) {
     if (m->d_tnodes) (void)hipFree(m->d_tnodes);
     if (m->d_tris) (void)hipFree(m->d_tris);
     if (m->d_normals) (void)hipFree(m->d_normals);
+    if (m->d_hot) (void)hipFree(m->d_hot);
     if (m->d_patches) (void)hipFree(m->d_patches);
     if (m->d_leaf_info) (void)hipFree(m->d_leaf_info);
     delete m;

@@ -38,6 +38,18 @@ struct alignas(16) DevTri {
 };
 static_assert(sizeof(DevTri) == 80, "triangle must be 5 x 16 B");
 
+// 32-byte companion of a threaded node for the single-precision pre-test: the
+// box rounded to f32, the skip link, and the leaf reference (0xFFFFFFFF = no
+// leaves, bit 31 clear = the node's only leaf, bit 31 set = several leaves, read
+// the range from the full node).
+struct alignas(16) HotNode {
+    float lo[3];
+    float hi[3];
+    uint32_t skip;
+    uint32_t leaf_ref;
+};
+static_assert(sizeof(HotNode) == 32, "hot node must be 2 x 16 B");
+
 struct DevMesh {
     const DevNode *nodes;        // reference order (children after descendants, root last)
     const DevNode *tnodes;       // pre-order, threaded with skip links
@@ -47,6 +59,9 @@ struct DevMesh {
     uint32_t root;
     uint32_t depth;
     uint32_t fast_div_ok;        // every box coordinate is 0 or has 2^-600 <= |c| <= 2^400
+    const HotNode *hot;               // pre-order, parallel to tnodes
+    float coord_max;                  // largest |box coordinate|
+    uint32_t f32_ok;                  // every box coordinate is 0 or has 2^-40 <= |c| <= 2^40
     const rtg_trispline *patches;     // non-null: leaves are facets of trispline patches
     const rtg_patch_leaf *leaf_info;  // per leaf: patch index and corner parameters
     uint32_t newton_steps;

@@ -22,6 +22,7 @@ struct PhasedTuning {
     uint32_t tri_min = 12;
     uint32_t obj_min = 8;
     uint32_t max_blocks = 1024;
+    uint32_t pretest = 1;        // single-precision box pre-test with exact fallback
     uint32_t stats = 0;          // diagnostics build: tally steps and lanes per phase
 };
 hipError_t launch_render_primary_phased(hipStream_t stream, const DevScene &s, const rtg_view &view, uint32_t width,

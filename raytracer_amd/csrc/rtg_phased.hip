@@ -152,6 +152,27 @@ __device__ __forceinline__ bool tri_hit_time_signs(V3 v0, V3 v1, V3 v2, const Ra
     return ok;
 }
 
+__device__ __forceinline__ float hw_minf(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float hw_maxf(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// Single-precision pre-test window (ray side): direction components 0 or in
+// [2^-40, 2^40], origin components 0 or in the same band; with the mesh's
+// coordinates in that band too, no f32 product below can overflow or go
+// subnormal, so every rounding is a relative 2^-24 error.
+__device__ __forceinline__ bool pre_ray_ok(const Ray &r) {
+    const double lo = 0x1p-40, hi = 0x1p40;
+    return in_window(r.d.x, lo, hi) && in_window(r.d.y, lo, hi) && in_window(r.d.z, lo, hi) &&
+           in_window(r.o.x, lo, hi) && in_window(r.o.y, lo, hi) && in_window(r.o.z, lo, hi);
+}
+typedef const HotNode __attribute__((address_space(1))) *GHotPtr;
+
 // Generic box test with IEEE divisions (any magnitudes).
 __device__ __forceinline__ bool box_hit_div(V3 lo, V3 hi, const Ray &r, double bound) {
     double mn = -kInf, mx = kInf;
@@ -237,12 +258,15 @@ struct PhasedParams {
 };
 
 // STATS builds add per-wave step/lane tallies into work_counters[8*kCounterStride ...] (diagnostics only).
-template <class Source, bool COUNT, bool POINTS, bool PATCH, bool STATS = false>
+template <class Source, bool COUNT, bool POINTS, bool PATCH, bool PRE, bool STATS = false>
 __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
                                                           uint32_t *work_counters, PhasedParams prm,
                                                           rtg_hit *out_hits, rtg_point *out_points,
                                                           rtg_ray_counters *out_counters) {
     uint32_t st_iter = 0, st_node = 0, st_node_l = 0, st_tri = 0, st_tri_l = 0, st_obj = 0, st_obj_l = 0, st_refill = 0;
+    uint32_t st_amb = 0, st_amb_l = 0;
+    uint64_t tk_node = 0, tk_tri = 0, tk_obj = 0, tk_all = 0, tk0 = 0, tk1 = 0;
+    if (STATS) tk_all = __builtin_amdgcn_s_memtime();
     WorkQueue wq;
     wq.counters = work_counters;
     wq.total_chunks = (uint32_t)((n_items + 63) >> 6);
@@ -256,14 +280,15 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
     // per-lane state
     uint32_t phase = PH_OBJ;      // every lane starts by asking for a ray
     bool has_ray = false;
-    uint64_t out_index = 0;
-    Ray ray{};                    // outer ray
+    // Per-ray state that is only touched between objects lives in LDS ([field][lane], 8-byte fields, so a
+    // wave's access is conflict-free): the outer ray, the output slot and the scene-level best hit.
+    __shared__ double cold[9 * kBlock];
+    double *cold_lane = cold + threadIdx.x;
+    enum { C_OX = 0, C_OY, C_OZ, C_DX, C_DY, C_DZ, C_BEST_T, C_BEST_ID, C_OUT };
+#define COLD(f) cold_lane[(f) * kBlock]
     Ray in{};                     // ray in the current object's space
     V3 rcp = mk(0, 0, 0);
     bool fast = false;
-    bool best_have = false;
-    double best_t = kInf;
-    uint32_t best_obj = RTG_NONE, best_leaf = RTG_NONE;
     Holder h;
     h.has = false;
     h.t = kInf;
@@ -271,6 +296,9 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
     uint32_t obj_i = 0, cur = 0, end = 0, leaf_cur = 0, leaf_end = 0;
     GNodePtr nodes = nullptr;
     GTriPtr tris = nullptr;
+    GHotPtr hot = nullptr;
+    bool pre = false;             // this ray/mesh pair may use the single-precision pre-test
+    float o32x = 0, o32y = 0, o32z = 0, r32x = 0, r32y = 0, r32z = 0, e2 = 0;
     const rtg_trispline *patches = nullptr;
     const rtg_patch_leaf *leaf_info = nullptr;
     uint32_t newton_steps = 0;
@@ -290,14 +318,17 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
             if (STATS) {
                 st_obj++;
                 st_obj_l += (uint32_t)__popcll(m_obj);
+                tk0 = __builtin_amdgcn_s_memtime();
             }
             // (1) a ray that has seen every object reports its closest hit
             if (phase == PH_OBJ && has_ray && obj_i >= s.n_objects) {
                 SceneHit sh;
-                sh.have = best_have;
-                sh.t = best_t;
-                sh.object = best_obj;
-                sh.leaf = best_leaf;
+                uint64_t best_id = (uint64_t)__double_as_longlong(COLD(C_BEST_ID));
+                uint64_t out_index = (uint64_t)__double_as_longlong(COLD(C_OUT));
+                sh.object = (uint32_t)best_id;
+                sh.leaf = (uint32_t)(best_id >> 32);
+                sh.have = sh.object != RTG_NONE;
+                sh.t = COLD(C_BEST_T);
                 if (out_hits) {
                     uint64_t tb = __double_as_longlong(sh.have ? sh.t : kInf);
                     uint4 v;
@@ -307,7 +338,10 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     v.w = (uint32_t)(tb >> 32);
                     *reinterpret_cast<uint4 *>(out_hits + out_index) = v;
                 }
-                if (POINTS) scene_point<PATCH>(s, ray, sh, out_points[out_index]);
+                if (POINTS) {
+                    Ray ray{mk(COLD(C_OX), COLD(C_OY), COLD(C_OZ)), mk(COLD(C_DX), COLD(C_DY), COLD(C_DZ))};
+                    scene_point<PATCH>(s, ray, sh, out_points[out_index]);
+                }
                 if (COUNT) {
                     out_counters[out_index].nodes_visited = ctr.nodes;
                     out_counters[out_index].tris_tested = ctr.tris;
@@ -332,13 +366,20 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 uint32_t n_take = n_need < chunk_left ? n_need : chunk_left;
                 if (phase == PH_OBJ && !has_ray && rank < n_take) {
                     uint64_t item = chunk_base + (64u - chunk_left) + rank;
+                    Ray ray;
+                    uint64_t out_index;
                     if (src.make(item, ray, out_index)) {
                         has_ray = true;
                         obj_i = 0;
-                        best_have = false;
-                        best_t = kInf;
-                        best_obj = RTG_NONE;
-                        best_leaf = RTG_NONE;
+                        COLD(C_OX) = ray.o.x;
+                        COLD(C_OY) = ray.o.y;
+                        COLD(C_OZ) = ray.o.z;
+                        COLD(C_DX) = ray.d.x;
+                        COLD(C_DY) = ray.d.y;
+                        COLD(C_DZ) = ray.d.z;
+                        COLD(C_OUT) = __longlong_as_double((long long)out_index);
+                        COLD(C_BEST_T) = kInf;
+                        COLD(C_BEST_ID) = __longlong_as_double(-1ll);   // object = leaf = RTG_NONE
                         ctr.nodes = 0;
                         ctr.tris = 0;
                     }
@@ -350,7 +391,10 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
             // (3) walk the object list up to the next mesh (spheres and planes are done in place)
             while (phase == PH_OBJ && has_ray && obj_i < s.n_objects) {
                 const DevObject &o = s.objects[obj_i];
-                in = inner_ray(o, ray);
+                {
+                    Ray ray{mk(COLD(C_OX), COLD(C_OY), COLD(C_OZ)), mk(COLD(C_DX), COLD(C_DY), COLD(C_DZ))};
+                    in = inner_ray(o, ray);
+                }
                 bool some = false;
                 double t = 0.0;
                 if (o.kind == RTG_SPHERE) {
@@ -370,22 +414,42 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     h.leaf = RTG_NONE;
                     fast = o.mesh.fast_div_ok != 0 && fast_div_ray_ok(in);
                     rcp = mk(1.0 / in.d.x, 1.0 / in.d.y, 1.0 / in.d.z);
+                    if (PRE) {
+                        hot = (GHotPtr)o.mesh.hot;
+                        pre = fast && o.mesh.f32_ok != 0 && pre_ray_ok(in);
+                        // q32 = (c32 - o32) * r32 differs from the reference's f64 plane time by at most
+                        // 4.1 * 2^-24 * (|c| + |o|) * |r|; e2 is twice a 2^-21 bound on it (axes with d = 0 get
+                        // r32 = NaN so their plane times are NaN and drop out of the min/max, as in the f64 test)
+                        const float qnan = __builtin_nanf("");
+                        o32x = (float)in.o.x;
+                        o32y = (float)in.o.y;
+                        o32z = (float)in.o.z;
+                        r32x = in.d.x == 0.0 ? qnan : (float)rcp.x;
+                        r32y = in.d.y == 0.0 ? qnan : (float)rcp.y;
+                        r32z = in.d.z == 0.0 ? qnan : (float)rcp.z;
+                        float b = o.mesh.coord_max;
+                        float ex = in.d.x == 0.0 ? 0.0f : (b + __builtin_fabsf(o32x)) * __builtin_fabsf(r32x);
+                        float ey = in.d.y == 0.0 ? 0.0f : (b + __builtin_fabsf(o32y)) * __builtin_fabsf(r32y);
+                        float ez = in.d.z == 0.0 ? 0.0f : (b + __builtin_fabsf(o32z)) * __builtin_fabsf(r32z);
+                        e2 = __builtin_fmaxf(ex, __builtin_fmaxf(ey, ez)) * 0x1p-20f;
+                    }
                     phase = PH_NODE;
                     break;
                 }
                 if (some) {
+                    double best_t = COLD(C_BEST_T);
+                    bool best_have = (uint32_t)__double_as_longlong(COLD(C_BEST_ID)) != RTG_NONE;
                     bool better = !best_have || (!is_nan(best_t) && (is_nan(t) || best_t > t));
                     if (better) {
-                        best_have = true;
-                        best_t = t;
-                        best_obj = obj_i;
-                        best_leaf = RTG_NONE;
+                        COLD(C_BEST_T) = t;
+                        COLD(C_BEST_ID) = __longlong_as_double((long long)(((uint64_t)RTG_NONE << 32) | obj_i));
                     }
                 }
                 obj_i++;
             }
             m_node = __ballot(phase == PH_NODE);
             m_tri = __ballot(phase == PH_TRI);
+            if (STATS) tk_obj += __builtin_amdgcn_s_memtime() - tk0;
         }
 
         // ---- one box test per lane ---------------------------------------------------
@@ -393,28 +457,77 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
             if (STATS) {
                 st_node++;
                 st_node_l += (uint32_t)__popcll(m_node);
+                tk0 = __builtin_amdgcn_s_memtime();
             }
             bool slow_any = __ballot(phase == PH_NODE && !fast) != 0;
+            bool pre_all = PRE && __ballot(phase == PH_NODE && !pre) == 0;
             if (phase == PH_NODE) {
-                V3 lo, hi;
-                uint4 tail;
-                load_node_g(nodes + cur, lo, hi, tail);
-                if (COUNT) ctr.nodes++;
-                double bound = holder_bound(h);
-                bool go = slow_any ? box_hit_div(lo, hi, in, bound) : box_hit_fast(lo, hi, in, rcp, bound);
-                if (go) {
-                    cur = cur + 1;
-                    if (tail.w != 0) {
-                        leaf_cur = tail.z;
-                        leaf_end = tail.z + tail.w;
-                        phase = PH_TRI;
+                bool go;
+                uint32_t skip, leaf_ref;
+                if (pre_all) {
+                    // single-precision pre-test on the 32-byte companion node
+                    typedef const vu4 __attribute__((address_space(1))) *U4;
+                    U4 hp = (U4)(hot + cur);
+                    vu4 h0 = hp[0], h1 = hp[1];
+                    float lx = __uint_as_float(h0.x), ly = __uint_as_float(h0.y), lz = __uint_as_float(h0.z);
+                    float ux = __uint_as_float(h0.w), uy = __uint_as_float(h1.x), uz = __uint_as_float(h1.y);
+                    skip = h1.z;
+                    leaf_ref = h1.w;
+                    if (COUNT) ctr.nodes++;
+                    float ax = (lx - o32x) * r32x, bx = (ux - o32x) * r32x;
+                    float ay = (ly - o32y) * r32y, by = (uy - o32y) * r32y;
+                    float az = (lz - o32z) * r32z, bz = (uz - o32z) * r32z;
+                    float mn = hw_maxf(hw_maxf(hw_minf(ax, bx), hw_minf(ay, by)), hw_maxf(hw_minf(az, bz), 0.0f));
+                    float mx = hw_minf(hw_minf(hw_maxf(ax, bx), hw_maxf(ay, by)), hw_maxf(az, bz));
+                    float g1 = mx - mn;                                   // NaN when every axis is skipped
+                    double g2 = holder_bound(h) - (double)mn;            // NaN when the held time is NaN
+                    double e2d = (double)e2;
+                    bool yes = g1 > e2 && g2 > e2d;
+                    bool no = g1 < -e2 || g2 < -e2d;
+                    go = yes;
+                    if (__ballot(!(yes || no)) != 0) {
+                        if (STATS) {
+                            st_amb++;
+                            st_amb_l += (uint32_t)__popcll(__ballot(!(yes || no)));
+                        }
+                        if (!(yes || no)) {      // too close to call in single precision: the exact test decides
+                            V3 lo, hi;
+                            uint4 tail;
+                            load_node_g(nodes + cur, lo, hi, tail);
+                            go = box_hit_fast(lo, hi, in, rcp, holder_bound(h));
+                        }
                     }
                 } else {
-                    cur = tail.x;
+                    V3 lo, hi;
+                    uint4 tail;
+                    load_node_g(nodes + cur, lo, hi, tail);
+                    if (COUNT) ctr.nodes++;
+                    double bound = holder_bound(h);
+                    go = slow_any ? box_hit_div(lo, hi, in, bound) : box_hit_fast(lo, hi, in, rcp, bound);
+                    skip = tail.x;
+                    leaf_ref = tail.w == 0 ? 0xFFFFFFFFu : (tail.w == 1 ? tail.z : 0x80000000u);
+                }
+                if (go) {
+                    if (leaf_ref != 0xFFFFFFFFu) {
+                        if (leaf_ref & 0x80000000u) {    // several leaves: the range lives in the full node
+                            typedef const vu4 __attribute__((address_space(1))) *U4;
+                            vu4 t = ((U4)(nodes + cur))[3];
+                            leaf_cur = t.z;
+                            leaf_end = t.z + t.w;
+                        } else {
+                            leaf_cur = leaf_ref;
+                            leaf_end = leaf_ref + 1;
+                        }
+                        phase = PH_TRI;
+                    }
+                    cur = cur + 1;
+                } else {
+                    cur = skip;
                 }
                 if (phase == PH_NODE && cur >= end) phase = PH_OBJ + 4;   // traversal finished (resolved below)
             }
             m_tri = __ballot(phase == PH_TRI);
+            if (STATS) tk_node += __builtin_amdgcn_s_memtime() - tk0;
         }
 
         // ---- one triangle per waiting lane ----------------------------------------------
@@ -422,6 +535,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
             if (STATS) {
                 st_tri++;
                 st_tri_l += (uint32_t)__popcll(m_tri);
+                tk0 = __builtin_amdgcn_s_memtime();
             }
             if (phase == PH_TRI) {
                 V3 v0, v1, v2;
@@ -440,17 +554,18 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 leaf_cur++;
                 if (leaf_cur >= leaf_end) phase = cur >= end ? PH_OBJ + 4 : PH_NODE;
             }
+            if (STATS) tk_tri += __builtin_amdgcn_s_memtime() - tk0;
         }
 
         // ---- a finished traversal reports to the scene-level minimum ------------------------
         if (phase == PH_OBJ + 4) {
             if (h.has) {
+                double best_t = COLD(C_BEST_T);
+                bool best_have = (uint32_t)__double_as_longlong(COLD(C_BEST_ID)) != RTG_NONE;
                 bool better = !best_have || (!is_nan(best_t) && (is_nan(h.t) || best_t > h.t));
                 if (better) {
-                    best_have = true;
-                    best_t = h.t;
-                    best_obj = obj_i;
-                    best_leaf = h.leaf;
+                    COLD(C_BEST_T) = h.t;
+                    COLD(C_BEST_ID) = __longlong_as_double((long long)(((uint64_t)h.leaf << 32) | obj_i));
                 }
             }
             obj_i++;
@@ -468,8 +583,17 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
         atomicAdd(st + 6, st_obj_l);
         atomicAdd(st + 7, st_refill);
         atomicAdd(st + 8, 1u);
+        atomicAdd(st + 9, st_amb);
+        atomicAdd(st + 10, st_amb_l);
+        tk1 = __builtin_amdgcn_s_memtime() - tk_all;
+        atomicAdd(st + 11, (uint32_t)(tk_node >> 6));   // 64-cycle units
+        atomicAdd(st + 12, (uint32_t)(tk_tri >> 6));
+        atomicAdd(st + 13, (uint32_t)(tk_obj >> 6));
+        atomicAdd(st + 14, (uint32_t)(tk1 >> 6));
     }
 }
+
+#undef COLD
 
 // ---- self-test of div_by_const against the hardware division ----------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t &st) {
@@ -543,9 +667,15 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     PhasedParams prm{tune.tri_min, tune.obj_min};
     dim3 g(grid), b(kBlock);
     bool count = out_counters != nullptr, points = out_points != nullptr;
-#define RTG_L(C, P, X, S)                                                                                          \
-    hipLaunchKernelGGL((k_trace_phased<Source, C, P, X, S>), g, b, 0, stream, s, src, n_items, work_counters, prm, \
-                       out_hits, out_points, out_counters)
+#define RTG_L(C, P, X, S)                                                                                   \
+    do {                                                                                                    \
+        if (tune.pretest)                                                                                   \
+            hipLaunchKernelGGL((k_trace_phased<Source, C, P, X, true, S>), g, b, 0, stream, s, src, n_items, \
+                               work_counters, prm, out_hits, out_points, out_counters);                     \
+        else                                                                                                \
+            hipLaunchKernelGGL((k_trace_phased<Source, C, P, X, false, S>), g, b, 0, stream, s, src, n_items, \
+                               work_counters, prm, out_hits, out_points, out_counters);                     \
+    } while (0)
     if (s.has_patches) {
         if (count && points) RTG_L(true, true, true, false);
         else if (count) RTG_L(true, false, true, false);
