@@ -5,7 +5,8 @@ A step is one pass of the hot path over one batch: a full 1920x1080 primary-ray 
 BVH traversal + ray/triangle intersection + closest hit -> 16-byte hit records) against the 1 000 000-triangle
 terrain, inputs (scene, BVH) resident in HBM, outputs written to HBM.  With N > 1 every rank renders its own
 frame of the sequence (frame f -> rank f mod N, camera moved per frame; BVH replicated) and the hit buffers are
-gathered to rank 0 with RCCL inside the timed region: weak scaling.
+gathered to rank 0 with RCCL inside the timed region, on a second stream so the gather of frame i overlaps the
+traversal of frame i+1 (two hit buffers per rank): weak scaling.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (k_trace_phased, the persistent traversal
 kernel behind rtg_render_primary) against HBM peak using ALGORITHMIC bytes (nodes visited x 64 B + triangles tested
@@ -65,6 +66,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="ctx option key=value (e.g. tri_min=16)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--grid", type=str, default=None, help="NXxNY quads (default 1000x500)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the gather path even with one rank (rehearses the multi-GPU step on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -74,10 +77,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
     if args.gpus != world:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
@@ -104,33 +110,46 @@ def main():
 
     n_rays = WIDTH * HEIGHT
     tile = (0, 0, WIDTH, HEIGHT)
-    hits = torch.empty(n_rays * 16, dtype=torch.uint8, device=dev)
+    hits2 = [torch.empty(n_rays * 16, dtype=torch.uint8, device=dev) for _ in range(2 if use_dist else 1)]
+    hits = hits2[0]
     sizes = [hits.numel()] * world
+    if use_dist:
+        comm = torch.cuda.Stream(dev)                 # gathers run here, traversal on `stream`
+        recv = [[torch.empty_like(hits) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+        rendered = [torch.cuda.Event() for _ in range(2)]
+        gathered = [torch.cuda.Event() for _ in range(2)]
 
     def step(i, ev=None):
         frame = i * world + rank
+        b = i & 1 if use_dist else 0
+        if use_dist:
+            stream.wait_event(gathered[b])            # hit buffer b is free once its previous gather has finished
         if ev is not None:
             ev[0].record(stream)
-        scene.render_primary_raw(frame_view(rtg, frame), WIDTH, HEIGHT, tile, hits.data_ptr())
+        scene.render_primary_raw(frame_view(rtg, frame), WIDTH, HEIGHT, tile, hits2[b].data_ptr())
         if ev is not None:
             ev[1].record(stream)
-        if world > 1:
-            shard.gather_to_root(hits, sizes, dst=0)      # RCCL gather of the finished framebuffers to rank 0
+        if use_dist:
+            rendered[b].record(stream)
+            comm.wait_event(rendered[b])
+            with torch.cuda.stream(comm):             # RCCL gather of the finished framebuffers to rank 0
+                shard.gather_to_root(hits2[b], sizes, dst=0, out=recv[b])
+                gathered[b].record(comm)
 
     for i in range(args.warmup):
         step(i)
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, events[i])
-    torch.cuda.synchronize(dev)
-    if world > 1:
+    torch.cuda.synchronize(dev)                       # both streams: every frame rendered and gathered
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -184,7 +203,8 @@ def main():
             "config": {"workload": f"config 2: {2 * nx * ny}-triangle terrain BVH ({bvh.n_nodes} nodes, depth {bvh.depth}), "
                                    f"{WIDTH}x{HEIGHT} primary rays per step per GPU, closest-hit ids",
                        "traversal": "library default" if args.traversal < 0 else ["short-stack", "threaded", "phased-threaded"][args.traversal],
-                       "parallelism": f"frames sharded over {world} GPU(s), BVH replicated" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "parallelism": f"frames sharded over {world} GPU(s), BVH replicated"
+                                      + (", RCCL gather to rank 0 overlapped with the next frame" if use_dist else ""),
                        "host_bvh_build_s": round(build_s, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if traffic is None else round(traffic / 1e9, 4), "traffic_unit": "GB per launch",
@@ -194,7 +214,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -51,19 +51,29 @@ def rect_pixels(rects: Sequence[Rect]) -> int:
     return sum(w * h for _, _, w, h in rects)
 
 
-def gather_to_root(local: torch.Tensor, sizes: Sequence[int], dst: int = 0, group=None):
+def gather_to_root(local: torch.Tensor, sizes: Sequence[int], dst: int = 0, group=None, out=None):
     """Gathers each rank's flat buffer (`sizes[r]` elements on rank r) to rank `dst`.
     Equal sizes use one `gather` collective; unequal sizes use grouped point-to-point sends, which is what RCCL
-    does for gather anyway.  Returns the list of per-rank tensors on `dst`, None elsewhere."""
+    does for gather anyway.  `out` (on `dst` only) is an optional list of preallocated per-rank receive tensors, so
+    a per-frame loop allocates nothing.  Returns the list of per-rank tensors on `dst`, None elsewhere.
+    The collective is enqueued on the caller's current stream."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     assert local.numel() == sizes[rank], (local.numel(), sizes[rank])
+    if out is not None and rank == dst:
+        assert len(out) == world and all(out[r].numel() == sizes[r] for r in range(world))
     if len(set(sizes)) == 1:
-        bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+        bufs = None
+        if rank == dst:
+            bufs = out if out is not None else [torch.empty_like(local) for _ in range(world)]
         dist.gather(local, bufs, dst=dst, group=group)
         return bufs
     if rank == dst:
-        bufs = [local if r == dst else torch.empty(sizes[r], dtype=local.dtype, device=local.device) for r in range(world)]
+        if out is not None:
+            out[dst].copy_(local)
+            bufs = list(out)
+        else:
+            bufs = [local if r == dst else torch.empty(sizes[r], dtype=local.dtype, device=local.device) for r in range(world)]
         ops = [dist.P2POp(dist.irecv, bufs[r], r, group) for r in range(world) if r != dst and sizes[r] > 0]
     else:
         bufs = None

@@ -103,6 +103,19 @@ def _worker_unequal(rank, world, port, result_path):
         bufs = shard.gather_to_root(local, sizes)
         if rank == 0:
             ok = all(torch.equal(bufs[r], torch.arange(sizes[r], dtype=torch.int32) + 100 * r) for r in range(world))
+        # preallocated receive buffers, unequal and equal sizes, reused over two rounds
+        out = [torch.full((n,), -1, dtype=torch.int32) for n in sizes] if rank == 0 else None
+        eq_out = [torch.full((4,), -1, dtype=torch.int32) for _ in range(world)] if rank == 0 else None
+        for rnd in range(2):
+            bufs = shard.gather_to_root(local + rnd, sizes, out=out)
+            eq = shard.gather_to_root(torch.full((4,), 10 * rank + rnd, dtype=torch.int32), [4] * world, out=eq_out)
+            if rank == 0:
+                ok = ok and all(bufs[r] is out[r] for r in range(world)) and all(eq[r] is eq_out[r] for r in range(world))
+                ok = ok and all(torch.equal(out[r], torch.arange(sizes[r], dtype=torch.int32) + 100 * r + rnd)
+                                for r in range(world))
+                ok = ok and all(torch.equal(eq_out[r], torch.full((4,), 10 * r + rnd, dtype=torch.int32))
+                                for r in range(world))
+        if rank == 0:
             with open(result_path, "w") as fh:
                 fh.write(str(int(ok)))
         dist.barrier()
