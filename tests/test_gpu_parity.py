@@ -160,6 +160,48 @@ def test_deep_tree_uses_every_stack_tier(gpu_ctx):
     gpu_ctx.set_option("traversal", 2)
 
 
+@pytest.mark.parametrize("exponent", [-45, -39, 0, 20, 39, 45])
+@pytest.mark.parametrize("pretest", [2, 1])
+def test_single_precision_pretest_borderline_cases(gpu_ctx, exponent, pretest):
+    """The f32 box pre-test of the default kernel must never change an answer: lattice geometry whose plane times
+    tie exactly (ray origins on box planes, dyadic directions, coincident hit and box times), geometry offset so far
+    that f32 cannot resolve the boxes, and scales on either side of the window in which the pre-test is allowed."""
+    gpu_ctx.set_option("traversal", 2)
+    gpu_ctx.set_option("pretest", pretest)
+    rng = np.random.default_rng(100 + exponent)
+    scale = 2.0 ** exponent
+    # lattice triangles: integer corners, slightly tilted so they are visible through their boxes
+    cells = rng.integers(-8, 8, size=(400, 1, 3)).astype(np.float64)
+    corners = np.array([[0, 0, 0], [1, 0, 1], [0, 1, 1]], dtype=np.float64)
+    lattice = cells + corners[rng.permuted(np.tile(np.arange(3), (400, 1)), axis=1)]
+    # far-offset cluster: boxes 1e-3 apart at coordinate 4096 (f32 spacing there is 4.9e-4)
+    far = 4096.0 + rng.uniform(0, 0.05, size=(200, 1, 3)) + rng.uniform(-2e-3, 2e-3, size=(200, 3, 3))
+    tris = np.concatenate([lattice, far]) * scale
+    bvh = rtg.HostBvh(tris)
+    objs, _, _ = scenes.mesh_scene_objects(rtg.transform(), with_default=False)
+    pair = scenes.Pair(gpu_ctx, objs, {0: bvh})
+    n = 30000
+    o = rng.integers(-10, 10, size=(n, 3)).astype(np.float64)             # on lattice planes
+    o[n // 2:] += rng.choice([0.0, 0.5, 0.25], size=(n - n // 2, 3))
+    d = rng.choice([-1.0, -0.5, 0.0, 0.25, 0.5, 1.0, 2.0], size=(n, 3))
+    d[(d == 0).all(axis=1)] = [1.0, 0.5, -1.0]
+    o2 = 4096.0 + rng.uniform(-0.1, 0.15, size=(n // 3, 3))
+    d2 = far.mean(axis=1)[rng.integers(0, 200, size=n // 3)] + rng.normal(scale=5e-4, size=(n // 3, 3)) - o2
+    o3 = rng.uniform(-10, 10, size=(n // 3, 3))                            # aimed at the far cluster
+    d3 = (4096.0 + rng.uniform(0, 0.05, size=(n // 3, 3))) - o3
+    rays = np.concatenate([np.concatenate([o, d], axis=1), np.concatenate([o2, d2], axis=1),
+                           np.concatenate([o3, d3], axis=1)])
+    rays[:, :3] *= scale
+    rays[: n // 2, 3:] *= scale                                             # direction length is free: t scales
+    g_hits, g_pts, g_ctr = pair.gpu.trace(rays, points=True, counters=True)
+    c_hits, c_pts, c_ctr = pair.cpu.trace(rays, points=True, counters=True)
+    gpu_ctx.set_option("pretest", 2)
+    _assert_hits_equal(g_hits, c_hits)
+    _assert_points_equal(g_pts, c_pts)
+    assert np.array_equal(g_ctr, c_ctr)
+    assert (g_hits["leaf"] != rtg.RTG_NONE).mean() > 0.05
+
+
 def test_empty_inputs(gpu_ctx):
     objs, lights, view = scenes.default_objects(0)
     pair = scenes.Pair(gpu_ctx, objs, {})
