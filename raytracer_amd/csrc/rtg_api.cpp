@@ -43,8 +43,8 @@ struct rtg_ctx {
 struct rtg_mesh {
     rtg_ctx *ctx = nullptr;
     DevMesh dev{};
-    void *d_nodes = nullptr, *d_tnodes = nullptr, *d_tris = nullptr, *d_normals = nullptr;
-    void *d_patches = nullptr, *d_leaf_info = nullptr, *d_hot = nullptr;
+    void *d_nodes = nullptr, *d_slab = nullptr, *d_normals = nullptr;
+    void *d_patches = nullptr, *d_leaf_info = nullptr;
     bool is_patches = false;
     double bounds[6] = {0, 0, 0, 0, 0, 0};
     uint64_t n_leaves = 0;
@@ -477,9 +477,54 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) {
             m->bounds[3 + k] = r.hi[k];
         }
     }
+    // single-precision companion nodes for the pre-test, and the windows inside which the reciprocal-based and the
+    // single-precision box tests are exact (see rtg_phased.hip)
+    std::vector<HotNode> hot(thr_nodes.size());
+    uint32_t fast_ok = 1, f32_ok = 1;
+    double cmax = 0.0;
+    for (size_t i = 0; i < thr_nodes.size(); i++) {
+        const DevNode &n = thr_nodes[i];
+        for (int k = 0; k < 3; k++) {
+            hot[i].planes[2 * k] = (float)n.lo[k];
+            hot[i].planes[2 * k + 1] = (float)n.hi[k];
+            for (double c : {n.lo[k], n.hi[k]}) {
+                double a = std::fabs(c);
+                if (!(c == 0.0 || (a >= 0x1p-600 && a <= 0x1p400))) fast_ok = 0;
+                if (!(c == 0.0 || (a >= 0x1p-40 && a <= 0x1p40))) f32_ok = 0;
+                if (a > cmax) cmax = a;
+            }
+        }
+        hot[i].skip = n.link;
+        hot[i].leaf_ref = n.leaf_count == 0 ? 0xFFFFFFFFu : (n.leaf_count == 1 ? n.leaf_begin : 0x80000000u);
+    }
+
+    // one slab: header, hot nodes, threaded nodes, triangles
+    const size_t n = thr_nodes.size();
+    const size_t off_hot = sizeof(MeshSlabHeader), off_tnodes = off_hot + n * sizeof(HotNode),
+                 off_tris = off_tnodes + n * sizeof(DevNode), slab_bytes = off_tris + tris.size() * sizeof(DevTri);
+    MeshSlabHeader header{};
     rc = upload(ctx, ref_nodes.data(), ref_nodes.size() * sizeof(DevNode), &m->d_nodes);
-    if (rc == RTG_OK) rc = upload(ctx, thr_nodes.data(), thr_nodes.size() * sizeof(DevNode), &m->d_tnodes);
-    if (rc == RTG_OK) rc = upload(ctx, tris.data(), tris.size() * sizeof(DevTri), &m->d_tris);
+    if (rc == RTG_OK) {
+        hipError_t e = hipMalloc(&m->d_slab, slab_bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            m->d_slab = nullptr;
+            rc = fail(ctx, e == hipErrorOutOfMemory ? RTG_E_NOMEM : RTG_E_HIP, "hipMalloc(%zu): %s", slab_bytes,
+                      hipGetErrorString(e));
+        }
+    }
+    auto put = [&](size_t off, const void *src, size_t bytes) {
+        if (rc != RTG_OK || bytes == 0) return;
+        hipError_t e = hipMemcpy((uint8_t *)m->d_slab + off, src, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            rc = fail(ctx, RTG_E_HIP, "hipMemcpy to the mesh slab: %s", hipGetErrorString(e));
+        }
+    };
+    put(0, &header, sizeof(header));
+    put(off_hot, hot.data(), n * sizeof(HotNode));
+    put(off_tnodes, thr_nodes.data(), n * sizeof(DevNode));
+    put(off_tris, tris.data(), tris.size() * sizeof(DevTri));
     if (rc == RTG_OK && bvh->vertex_normals)
         rc = upload(ctx, bvh->vertex_normals, (size_t)bvh->n_leaves * 9 * sizeof(double), &m->d_normals);
     if (rc != RTG_OK) {
@@ -487,50 +532,17 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) {
         return rc;
     }
     m->dev.nodes = (const DevNode *)m->d_nodes;
-    m->dev.tnodes = (const DevNode *)m->d_tnodes;
-    m->dev.tris = (const DevTri *)m->d_tris;
+    m->dev.slab = (const uint8_t *)m->d_slab;
+    m->dev.tnodes = (const DevNode *)(m->dev.slab + off_tnodes);
+    m->dev.tris = (const DevTri *)(m->dev.slab + off_tris);
     m->dev.normals = (const double *)m->d_normals;
-    m->dev.n_nodes = (uint32_t)thr_nodes.size();
+    m->dev.n_nodes = (uint32_t)n;
     m->dev.root = bvh->root;
     m->dev.depth = depth;
-    // window inside which the reciprocal-based box test is exact (see rtg_phased.hip)
-    uint32_t fast_ok = 1;
-    for (const DevNode &n : thr_nodes)
-        for (int k = 0; k < 3 && fast_ok; k++)
-            for (double c : {n.lo[k], n.hi[k]}) {
-                double a = std::fabs(c);
-                if (!(c == 0.0 || (a >= 0x1p-600 && a <= 0x1p400))) fast_ok = 0;
-            }
     m->dev.fast_div_ok = fast_ok;
-    // single-precision companion nodes for the pre-test
-    {
-        std::vector<HotNode> hot(thr_nodes.size());
-        uint32_t f32_ok = 1;
-        double cmax = 0.0;
-        for (size_t i = 0; i < thr_nodes.size(); i++) {
-            const DevNode &n = thr_nodes[i];
-            for (int k = 0; k < 3; k++) {
-                hot[i].lo[k] = (float)n.lo[k];
-                hot[i].hi[k] = (float)n.hi[k];
-                for (double c : {n.lo[k], n.hi[k]}) {
-                    double a = std::fabs(c);
-                    if (!(c == 0.0 || (a >= 0x1p-40 && a <= 0x1p40))) f32_ok = 0;
-                    if (a > cmax) cmax = a;
-                }
-            }
-            hot[i].skip = n.link;
-            hot[i].leaf_ref = n.leaf_count == 0 ? 0xFFFFFFFFu : (n.leaf_count == 1 ? n.leaf_begin : 0x80000000u);
-        }
-        rc = upload(ctx, hot.data(), hot.size() * sizeof(HotNode), &m->d_hot);
-        if (rc != RTG_OK) {
-            rtg_mesh_destroy(m);
-            return rc;
-        }
-        m->dev.hot = (const HotNode *)m->d_hot;
-        m->dev.f32_ok = f32_ok && std::isfinite(cmax) ? 1u : 0u;
-        // rounded up so the kernel's error bound never under-estimates
-        m->dev.coord_max = std::nextafter((float)cmax, std::numeric_limits<float>::infinity());
-    }
+    m->dev.f32_ok = f32_ok && std::isfinite(cmax) ? 1u : 0u;
+    // rounded up so the kernel's error bound never under-estimates
+    m->dev.coord_max = std::nextafter((float)cmax, std::numeric_limits<float>::infinity());
     *out = m;
     return RTG_OK;
 }
@@ -539,10 +551,8 @@ void rtg_mesh_destroy(rtg_mesh *m) {
     if (!m) return;
     if (m->ctx) (void)hipSetDevice(m->ctx->device);
     if (m->d_nodes) (void)hipFree(m->d_nodes);
-    if (m->d_tnodes) (void)hipFree(m->d_tnodes);
-    if (m->d_tris) (void)hipFree(m->d_tris);
+    if (m->d_slab) (void)hipFree(m->d_slab);
     if (m->d_normals) (void)hipFree(m->d_normals);
-    if (m->d_hot) (void)hipFree(m->d_hot);
     if (m->d_patches) (void)hipFree(m->d_patches);
     if (m->d_leaf_info) (void)hipFree(m->d_leaf_info);
     delete m;
@@ -570,6 +580,16 @@ int rtg_mesh_create_patches(rtg_ctx *ctx, const rtg_bvh *bvh, const rtg_patch_se
     if (rc != RTG_OK) {
         rtg_mesh_destroy(m);
         return rc;
+    }
+    MeshSlabHeader header{};
+    header.patches = (const rtg_trispline *)m->d_patches;
+    header.leaf_info = (const rtg_patch_leaf *)m->d_leaf_info;
+    header.newton_steps = ps->newton_steps;
+    hipError_t he = hipMemcpy(m->d_slab, &header, sizeof(header), hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        (void)hipGetLastError();
+        rtg_mesh_destroy(m);
+        return fail(ctx, RTG_E_HIP, "hipMemcpy of the patch header: %s", hipGetErrorString(he));
     }
     m->is_patches = true;
     m->dev.patches = (const rtg_trispline *)m->d_patches;
@@ -652,8 +672,12 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
     s->dev.overflow_levels = 0;
     s->dev.overflow_stride = 1;
     s->dev.has_patches = 0;
-    for (uint32_t i = 0; i < desc->n_objects; i++)
-        if (desc->objects[i].kind == RTG_PATCHES) s->dev.has_patches = 1;
+    s->dev.any_f32_ok = 0;
+    for (uint32_t i = 0; i < desc->n_objects; i++) {
+        const rtg_object &o = desc->objects[i];
+        if (o.kind == RTG_PATCHES) s->dev.has_patches = 1;
+        if ((o.kind == RTG_MESH || o.kind == RTG_PATCHES) && o.mesh->dev.f32_ok) s->dev.any_f32_ok = 1;
+    }
     *out = s;
     return RTG_OK;
 }

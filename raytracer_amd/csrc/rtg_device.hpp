@@ -39,16 +39,30 @@ struct alignas(16) DevTri {
 static_assert(sizeof(DevTri) == 80, "triangle must be 5 x 16 B");
 
 // 32-byte companion of a threaded node for the single-precision pre-test: the
-// box rounded to f32, the skip link, and the leaf reference (0xFFFFFFFF = no
-// leaves, bit 31 clear = the node's only leaf, bit 31 set = several leaves, read
-// the range from the full node).
+// box rounded to f32 with the two planes of an axis side by side (lo.x, hi.x,
+// lo.y, hi.y, lo.z, hi.z: one packed f32 operation handles an axis), the skip
+// link, and the leaf reference (0xFFFFFFFF = no leaves, bit 31 clear = the
+// node's only leaf, bit 31 set = several leaves, read the range from the full
+// node).
 struct alignas(16) HotNode {
-    float lo[3];
-    float hi[3];
+    float planes[6];
     uint32_t skip;
     uint32_t leaf_ref;
 };
 static_assert(sizeof(HotNode) == 32, "hot node must be 2 x 16 B");
+
+// Everything the persistent kernel reads of a mesh sits in one allocation so a
+// lane keeps one pointer per mesh:
+//   [MeshSlabHeader 64 B][HotNode x n_nodes][threaded DevNode x n_nodes][DevTri x n_leaves]
+// hot node i at +64 + 32 i, threaded node i at +64 + 32 n + 64 i, triangle l at
+// +64 + 96 n + 80 l (all 16-byte aligned).
+struct alignas(16) MeshSlabHeader {
+    const rtg_trispline *patches;     // non-null: leaves are facets of trispline patches
+    const rtg_patch_leaf *leaf_info;
+    uint32_t newton_steps;
+    uint32_t pad[11];
+};
+static_assert(sizeof(MeshSlabHeader) == 64, "slab header must be 64 B");
 
 struct DevMesh {
     const DevNode *nodes;        // reference order (children after descendants, root last)
@@ -59,7 +73,7 @@ struct DevMesh {
     uint32_t root;
     uint32_t depth;
     uint32_t fast_div_ok;        // every box coordinate is 0 or has 2^-600 <= |c| <= 2^400
-    const HotNode *hot;               // pre-order, parallel to tnodes
+    const uint8_t *slab;              // MeshSlabHeader + hot nodes + threaded nodes + triangles (tnodes, tris point into it)
     float coord_max;                  // largest |box coordinate|
     uint32_t f32_ok;                  // every box coordinate is 0 or has 2^-40 <= |c| <= 2^40
     const rtg_trispline *patches;     // non-null: leaves are facets of trispline patches
@@ -97,6 +111,7 @@ struct DevScene {
     uint32_t overflow_levels;    // levels available per thread in the slab
     uint32_t overflow_stride;    // threads the slab was sized for
     uint32_t has_patches;        // some object is a trispline patch set: launch the PATCH kernel variants
+    uint32_t any_f32_ok;         // some mesh allows the single-precision box pre-test
 };
 
 // ------------------------------------------------------------------- math --

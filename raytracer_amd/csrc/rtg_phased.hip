@@ -162,6 +162,22 @@ __device__ __forceinline__ float hw_maxf(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ float hw_max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float hw_min3f(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float hw_max0f(float a) {      // max(a, 0), NaN -> 0
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+typedef float vf2 __attribute__((ext_vector_type(2)));
 // Single-precision pre-test window (ray side): direction components 0 or in
 // [2^-40, 2^40], origin components 0 or in the same band; with the mesh's
 // coordinates in that band too, no f32 product below can overflow or go
@@ -171,7 +187,7 @@ __device__ __forceinline__ bool pre_ray_ok(const Ray &r) {
     return in_window(r.d.x, lo, hi) && in_window(r.d.y, lo, hi) && in_window(r.d.z, lo, hi) &&
            in_window(r.o.x, lo, hi) && in_window(r.o.y, lo, hi) && in_window(r.o.z, lo, hi);
 }
-typedef const HotNode __attribute__((address_space(1))) *GHotPtr;
+typedef const uint8_t __attribute__((address_space(1))) *GBytePtr;
 
 // Generic box test with IEEE divisions (any magnitudes).
 __device__ __forceinline__ bool box_hit_div(V3 lo, V3 hi, const Ray &r, double bound) {
@@ -287,21 +303,20 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
     enum { C_OX = 0, C_OY, C_OZ, C_DX, C_DY, C_DZ, C_BEST_T, C_BEST_ID, C_OUT };
 #define COLD(f) cold_lane[(f) * kBlock]
     Ray in{};                     // ray in the current object's space
+    // Builds without the pre-test keep the reciprocal direction for the division-free f64 box test; builds with
+    // it spend those registers on the f32 ray instead and use IEEE division wherever the pre-test cannot decide.
     V3 rcp = mk(0, 0, 0);
     bool fast = false;
-    Holder h;
+    Holder h;                     // invariant: t == +inf while empty, so h.t is the box test's bound as it stands
     h.has = false;
     h.t = kInf;
     h.leaf = RTG_NONE;
     uint32_t obj_i = 0, cur = 0, end = 0, leaf_cur = 0, leaf_end = 0;
-    GNodePtr nodes = nullptr;
-    GTriPtr tris = nullptr;
-    GHotPtr hot = nullptr;
+    GBytePtr slab = nullptr;      // the current mesh's hot-node array (slab + 64); everything else is an offset
     bool pre = false;             // this ray/mesh pair may use the single-precision pre-test
-    float o32x = 0, o32y = 0, o32z = 0, r32x = 0, r32y = 0, r32z = 0, e2 = 0;
-    const rtg_trispline *patches = nullptr;
-    const rtg_patch_leaf *leaf_info = nullptr;
-    uint32_t newton_steps = 0;
+    // single-precision ray for the pre-test: reciprocal direction, -(origin * reciprocal), error bound, and the
+    // holder's bound rounded to f32
+    float r32x = 0, r32y = 0, r32z = 0, np32x = 0, np32y = 0, np32z = 0, e2 = 0, b32 = 0;
     Counter ctr;
     ctr.nodes = 0;
     ctr.tris = 0;
@@ -402,36 +417,39 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 } else if (o.kind == RTG_PLANE) {
                     some = plane_hit_time(ld3(o.plane_position), ld3(o.plane_tan1), ld3(o.plane_tan2), in, t);
                 } else if ((o.kind == RTG_MESH || o.kind == RTG_PATCHES) && o.mesh.n_nodes != 0) {
-                    nodes = (GNodePtr)o.mesh.tnodes;
-                    tris = (GTriPtr)o.mesh.tris;
-                    patches = o.mesh.patches;
-                    leaf_info = o.mesh.leaf_info;
-                    newton_steps = o.mesh.newton_steps;
+                    slab = (GBytePtr)o.mesh.slab + sizeof(MeshSlabHeader);
                     end = o.mesh.n_nodes;
                     cur = 0;
                     h.has = false;
                     h.t = kInf;
                     h.leaf = RTG_NONE;
-                    fast = o.mesh.fast_div_ok != 0 && fast_div_ray_ok(in);
-                    rcp = mk(1.0 / in.d.x, 1.0 / in.d.y, 1.0 / in.d.z);
+                    if (!PRE) {
+                        fast = o.mesh.fast_div_ok != 0 && fast_div_ray_ok(in);
+                        rcp = mk(1.0 / in.d.x, 1.0 / in.d.y, 1.0 / in.d.z);
+                    }
                     if (PRE) {
-                        hot = (GHotPtr)o.mesh.hot;
-                        pre = fast && o.mesh.f32_ok != 0 && pre_ray_ok(in);
-                        // q32 = (c32 - o32) * r32 differs from the reference's f64 plane time by at most
-                        // 4.1 * 2^-24 * (|c| + |o|) * |r|; e2 is twice a 2^-21 bound on it (axes with d = 0 get
-                        // r32 = NaN so their plane times are NaN and drop out of the min/max, as in the f64 test)
+                        pre = o.mesh.f32_ok != 0 && pre_ray_ok(in);
+                        // q32 = fma(c32, r32, -(o32 * r32)) differs from the reference's f64 plane time (c - o) / d by at
+                        // most 2^-24 * (3|c| + 4|o|) * |r| (roundings of c, o, r to f32, of the product o32 * r32 and
+                        // of the fma); e2 = 16 * 2^-24 * (B + |o|) * |r| is twice what the difference of two such
+                        // times can be off by, and twice what a time minus the f32-rounded bound can be off by while
+                        // the bound is below 4 (B + |o|) |r| (above that the comparison is not close).  Axes with
+                        // d = 0 get r32 = NaN, so their plane times are NaN and drop out of the min/max as in the
+                        // f64 test.
                         const float qnan = __builtin_nanf("");
-                        o32x = (float)in.o.x;
-                        o32y = (float)in.o.y;
-                        o32z = (float)in.o.z;
-                        r32x = in.d.x == 0.0 ? qnan : (float)rcp.x;
-                        r32y = in.d.y == 0.0 ? qnan : (float)rcp.y;
-                        r32z = in.d.z == 0.0 ? qnan : (float)rcp.z;
+                        float o32x = (float)in.o.x, o32y = (float)in.o.y, o32z = (float)in.o.z;
+                        r32x = in.d.x == 0.0 ? qnan : (float)(1.0 / in.d.x);
+                        r32y = in.d.y == 0.0 ? qnan : (float)(1.0 / in.d.y);
+                        r32z = in.d.z == 0.0 ? qnan : (float)(1.0 / in.d.z);
+                        np32x = -(o32x * r32x);
+                        np32y = -(o32y * r32y);
+                        np32z = -(o32z * r32z);
                         float b = o.mesh.coord_max;
                         float ex = in.d.x == 0.0 ? 0.0f : (b + __builtin_fabsf(o32x)) * __builtin_fabsf(r32x);
                         float ey = in.d.y == 0.0 ? 0.0f : (b + __builtin_fabsf(o32y)) * __builtin_fabsf(r32y);
                         float ez = in.d.z == 0.0 ? 0.0f : (b + __builtin_fabsf(o32z)) * __builtin_fabsf(r32z);
                         e2 = __builtin_fmaxf(ex, __builtin_fmaxf(ey, ez)) * 0x1p-20f;
+                        b32 = __builtin_inff();          // == (float)h.t: an empty holder keeps t = +inf
                     }
                     phase = PH_NODE;
                     break;
@@ -459,31 +477,32 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 st_node_l += (uint32_t)__popcll(m_node);
                 tk0 = __builtin_amdgcn_s_memtime();
             }
-            bool slow_any = __ballot(phase == PH_NODE && !fast) != 0;
+            bool slow_any = PRE || __ballot(phase == PH_NODE && !fast) != 0;
             bool pre_all = PRE && __ballot(phase == PH_NODE && !pre) == 0;
             if (phase == PH_NODE) {
+                GNodePtr node = (GNodePtr)(slab + (uint64_t)end * sizeof(HotNode)) + cur;   // the full f64 node
                 bool go;
                 uint32_t skip, leaf_ref;
                 if (pre_all) {
                     // single-precision pre-test on the 32-byte companion node
                     typedef const vu4 __attribute__((address_space(1))) *U4;
-                    U4 hp = (U4)(hot + cur);
+                    U4 hp = (U4)(slab + (uint64_t)cur * sizeof(HotNode));
                     vu4 h0 = hp[0], h1 = hp[1];
-                    float lx = __uint_as_float(h0.x), ly = __uint_as_float(h0.y), lz = __uint_as_float(h0.z);
-                    float ux = __uint_as_float(h0.w), uy = __uint_as_float(h1.x), uz = __uint_as_float(h1.y);
+                    vf2 cx = {__uint_as_float(h0.x), __uint_as_float(h0.y)};   // lo.x, hi.x
+                    vf2 cy = {__uint_as_float(h0.z), __uint_as_float(h0.w)};
+                    vf2 cz = {__uint_as_float(h1.x), __uint_as_float(h1.y)};
                     skip = h1.z;
                     leaf_ref = h1.w;
                     if (COUNT) ctr.nodes++;
-                    float ax = (lx - o32x) * r32x, bx = (ux - o32x) * r32x;
-                    float ay = (ly - o32y) * r32y, by = (uy - o32y) * r32y;
-                    float az = (lz - o32z) * r32z, bz = (uz - o32z) * r32z;
-                    float mn = hw_maxf(hw_maxf(hw_minf(ax, bx), hw_minf(ay, by)), hw_maxf(hw_minf(az, bz), 0.0f));
-                    float mx = hw_minf(hw_minf(hw_maxf(ax, bx), hw_maxf(ay, by)), hw_maxf(az, bz));
+                    vf2 qx = __builtin_elementwise_fma(cx, (vf2){r32x, r32x}, (vf2){np32x, np32x});
+                    vf2 qy = __builtin_elementwise_fma(cy, (vf2){r32y, r32y}, (vf2){np32y, np32y});
+                    vf2 qz = __builtin_elementwise_fma(cz, (vf2){r32z, r32z}, (vf2){np32z, np32z});
+                    float mn = hw_max0f(hw_max3f(hw_minf(qx.x, qx.y), hw_minf(qy.x, qy.y), hw_minf(qz.x, qz.y)));
+                    float mx = hw_min3f(hw_maxf(qx.x, qx.y), hw_maxf(qy.x, qy.y), hw_maxf(qz.x, qz.y));
                     float g1 = mx - mn;                                   // NaN when every axis is skipped
-                    double g2 = holder_bound(h) - (double)mn;            // NaN when the held time is NaN
-                    double e2d = (double)e2;
-                    bool yes = g1 > e2 && g2 > e2d;
-                    bool no = g1 < -e2 || g2 < -e2d;
+                    float g2 = b32 - mn;                                  // NaN when the held time is NaN
+                    bool yes = g1 > e2 && g2 > e2;
+                    bool no = g1 < -e2 || g2 < -e2;
                     go = yes;
                     if (__ballot(!(yes || no)) != 0) {
                         if (STATS) {
@@ -493,17 +512,16 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                         if (!(yes || no)) {      // too close to call in single precision: the exact test decides
                             V3 lo, hi;
                             uint4 tail;
-                            load_node_g(nodes + cur, lo, hi, tail);
-                            go = box_hit_fast(lo, hi, in, rcp, holder_bound(h));
+                            load_node_g(node, lo, hi, tail);
+                            go = box_hit_div(lo, hi, in, h.t);
                         }
                     }
                 } else {
                     V3 lo, hi;
                     uint4 tail;
-                    load_node_g(nodes + cur, lo, hi, tail);
+                    load_node_g(node, lo, hi, tail);
                     if (COUNT) ctr.nodes++;
-                    double bound = holder_bound(h);
-                    go = slow_any ? box_hit_div(lo, hi, in, bound) : box_hit_fast(lo, hi, in, rcp, bound);
+                    go = slow_any ? box_hit_div(lo, hi, in, h.t) : box_hit_fast(lo, hi, in, rcp, h.t);
                     skip = tail.x;
                     leaf_ref = tail.w == 0 ? 0xFFFFFFFFu : (tail.w == 1 ? tail.z : 0x80000000u);
                 }
@@ -511,7 +529,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     if (leaf_ref != 0xFFFFFFFFu) {
                         if (leaf_ref & 0x80000000u) {    // several leaves: the range lives in the full node
                             typedef const vu4 __attribute__((address_space(1))) *U4;
-                            vu4 t = ((U4)(nodes + cur))[3];
+                            vu4 t = ((U4)node)[3];
                             leaf_cur = t.z;
                             leaf_end = t.z + t.w;
                         } else {
@@ -539,17 +557,20 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
             }
             if (phase == PH_TRI) {
                 V3 v0, v1, v2;
-                load_tri_g(tris + leaf_cur, v0, v1, v2);
+                load_tri_g((GTriPtr)(slab + (uint64_t)end * (sizeof(HotNode) + sizeof(DevNode))) + leaf_cur, v0, v1, v2);
                 double t;
                 bool some;
-                if (PATCH && patches) {
+                const MeshSlabHeader *hdr = (const MeshSlabHeader *)(const uint8_t *)(slab - sizeof(MeshSlabHeader));
+                if (PATCH && hdr->patches) {
                     PatchHit ph;
-                    some = patch_leaf_hit<false>(patches, leaf_info + leaf_cur, newton_steps, v0, v1, v2, in, ph);
+                    some = patch_leaf_hit<false>(hdr->patches, hdr->leaf_info + leaf_cur, hdr->newton_steps, v0, v1, v2,
+                                                 in, ph);
                     t = ph.tau;
                 } else {
                     some = tri_hit_time_signs(v0, v1, v2, in, t);
                 }
                 holder_add(h, some, t, leaf_cur);
+                if (PRE) b32 = (float)h.t;       // an empty holder keeps t = +inf
                 if (COUNT) ctr.tris++;
                 leaf_cur++;
                 if (leaf_cur >= leaf_end) phase = cur >= end ? PH_OBJ + 4 : PH_NODE;
@@ -669,7 +690,7 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     bool count = out_counters != nullptr, points = out_points != nullptr;
 #define RTG_L(C, P, X, S)                                                                                   \
     do {                                                                                                    \
-        if (tune.pretest)                                                                                   \
+        if (tune.pretest && s.any_f32_ok)                                                                   \
             hipLaunchKernelGGL((k_trace_phased<Source, C, P, X, true, S>), g, b, 0, stream, s, src, n_items, \
                                work_counters, prm, out_hits, out_points, out_counters);                     \
         else                                                                                                \
