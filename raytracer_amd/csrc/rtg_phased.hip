@@ -46,12 +46,25 @@ struct PrimarySource {
     rtg_rect tile;
     uint32_t tiles_x;     // 8x8 tiles per row of the rectangle
     // item -> pixel: items are numbered tile by tile, 64 per tile, row-major inside the tile
-    __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
+    __device__ __forceinline__ bool locate(uint64_t item, uint32_t &px, uint32_t &py, uint64_t &out_index) const {
         uint32_t t = (uint32_t)(item >> 6), l = (uint32_t)item & 63u;
         uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
-        uint32_t px = tx * 8 + (l & 7u), py = ty * 8 + (l >> 3);
+        px = tx * 8 + (l & 7u);
+        py = ty * 8 + (l >> 3);
         if (px >= tile.w || py >= tile.h) return false;
         out_index = (uint64_t)py * tile.w + px;
+        return true;
+    }
+    // output slot of an item that make() accepts
+    __device__ __forceinline__ uint64_t slot_of(uint64_t item) const {
+        uint32_t px, py;
+        uint64_t out_index = 0;
+        (void)locate(item, px, py, out_index);
+        return out_index;
+    }
+    __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
+        uint32_t px, py;
+        if (!locate(item, px, py, out_index)) return false;
         ray = primary_ray(view, tile.x0 + px, tile.y0 + py, width, height);
         return true;
     }
@@ -59,6 +72,7 @@ struct PrimarySource {
 struct BatchSource {
     const double *rays6;
     uint64_t n;
+    __device__ __forceinline__ uint64_t slot_of(uint64_t item) const { return item; }
     __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
         if (item >= n) return false;
         const double2 *q = reinterpret_cast<const double2 *>(rays6 + item * 6);
@@ -268,6 +282,32 @@ struct WorkQueue {
     }
 };
 
+// The ray of the single-precision box pre-test: q32 = fma(c32, r32, -(o32 * r32)) differs from the reference's f64
+// plane time (c - o) / d by at most 2^-24 * (3|c| + 4|o|) * |r| (roundings of c, o, r to f32, of the product
+// o32 * r32 and of the fma); e2 = 16 * 2^-24 * (B + |o|) * |r|, B the mesh's largest |coordinate|, is twice what the
+// difference of two such times can be off by, and twice what a time minus the f32-rounded bound can be off by while
+// the bound is below 4 (B + |o|) |r| (above that the comparison is not close).  Axes with d = 0 get r32 = NaN, so
+// their plane times are NaN and drop out of the min/max exactly as in the f64 test.
+struct PreRay {
+    float rx, ry, rz, nx, ny, nz, e2;
+};
+__device__ __forceinline__ PreRay make_pre_ray(const Ray &in, float coord_max) {
+    const float qnan = __builtin_nanf("");
+    float ox = (float)in.o.x, oy = (float)in.o.y, oz = (float)in.o.z;
+    PreRay p;
+    p.rx = in.d.x == 0.0 ? qnan : (float)(1.0 / in.d.x);
+    p.ry = in.d.y == 0.0 ? qnan : (float)(1.0 / in.d.y);
+    p.rz = in.d.z == 0.0 ? qnan : (float)(1.0 / in.d.z);
+    p.nx = -(ox * p.rx);
+    p.ny = -(oy * p.ry);
+    p.nz = -(oz * p.rz);
+    float ex = in.d.x == 0.0 ? 0.0f : (coord_max + __builtin_fabsf(ox)) * __builtin_fabsf(p.rx);
+    float ey = in.d.y == 0.0 ? 0.0f : (coord_max + __builtin_fabsf(oy)) * __builtin_fabsf(p.ry);
+    float ez = in.d.z == 0.0 ? 0.0f : (coord_max + __builtin_fabsf(oz)) * __builtin_fabsf(p.rz);
+    p.e2 = __builtin_fmaxf(ex, __builtin_fmaxf(ey, ez)) * 0x1p-20f;
+    return p;
+}
+
 struct PhasedParams {
     uint32_t tri_min;     // run a TRI step once this many lanes wait for one
     uint32_t obj_min;     // same for the between-objects step
@@ -302,6 +342,19 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
     double *cold_lane = cold + threadIdx.x;
     enum { C_OX = 0, C_OY, C_OZ, C_DX, C_DY, C_DZ, C_BEST_T, C_BEST_ID, C_OUT };
 #define COLD(f) cold_lane[(f) * kBlock]
+    // When the scene's first object is a mesh, a wave that takes a new 64-item chunk prepares all 64 rays at once
+    // (ray generation, transform into the mesh's space, pre-test ray) with every lane busy and parks them here
+    // ([field][slot of the wave]); a lane that later needs a ray only copies one slot.
+    __shared__ double stage_d[6 * kBlock];
+    __shared__ uint32_t stage_u[8 * kBlock];
+#define STG_D(slot, f) stage_d[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
+#define STG_U(slot, f) stage_u[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
+    bool stage0 = false;          // wave-uniform
+    if (s.n_objects != 0) {
+        const DevObject &o0 = s.objects[0];
+        stage0 = (o0.kind == RTG_MESH || o0.kind == RTG_PATCHES) && o0.mesh.n_nodes != 0;
+    }
+    const bool need_outer = POINTS || s.n_objects > 1;   // the outer ray is used again after the first object
     Ray in{};                     // ray in the current object's space
     // Builds without the pre-test keep the reciprocal direction for the division-free f64 box test; builds with
     // it spend those registers on the f32 ray instead and use IEEE division wherever the pre-test cannot decide.
@@ -311,7 +364,8 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
     h.has = false;
     h.t = kInf;
     h.leaf = RTG_NONE;
-    uint32_t obj_i = 0, cur = 0, end = 0, leaf_cur = 0, leaf_end = 0;
+    uint32_t obj_i = 0, cur = 0, end = 0;
+    uint32_t leaf_cur = 0;        // next leaf to test; bit 31: the node (cur - 1) has several leaves, its range ends the TRI phase
     GBytePtr slab = nullptr;      // the current mesh's hot-node array (slab + 64); everything else is an offset
     bool pre = false;             // this ray/mesh pair may use the single-precision pre-test
     // single-precision ray for the pre-test: reciprocal direction, -(origin * reciprocal), error bound, and the
@@ -375,28 +429,108 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     }
                     chunk_base = (uint64_t)chunk << 6;
                     chunk_left = 64;
+                    if (stage0) {           // every lane prepares one ray of the chunk
+                        const DevObject &o0 = s.objects[0];
+                        Ray ray;
+                        uint64_t out_index;
+                        uint32_t flags = 0;
+                        if (src.make(chunk_base + (threadIdx.x & 63u), ray, out_index)) {
+                            Ray in0 = inner_ray(o0, ray);
+                            flags = 1u;
+                            STG_D(threadIdx.x & 63u, 0) = in0.o.x;
+                            STG_D(threadIdx.x & 63u, 1) = in0.o.y;
+                            STG_D(threadIdx.x & 63u, 2) = in0.o.z;
+                            STG_D(threadIdx.x & 63u, 3) = in0.d.x;
+                            STG_D(threadIdx.x & 63u, 4) = in0.d.y;
+                            STG_D(threadIdx.x & 63u, 5) = in0.d.z;
+                            if (PRE) {
+                                if (o0.mesh.f32_ok != 0 && pre_ray_ok(in0)) flags |= 2u;
+                                PreRay pr = make_pre_ray(in0, o0.mesh.coord_max);
+                                STG_U(threadIdx.x & 63u, 0) = __float_as_uint(pr.rx);
+                                STG_U(threadIdx.x & 63u, 1) = __float_as_uint(pr.ry);
+                                STG_U(threadIdx.x & 63u, 2) = __float_as_uint(pr.rz);
+                                STG_U(threadIdx.x & 63u, 3) = __float_as_uint(pr.nx);
+                                STG_U(threadIdx.x & 63u, 4) = __float_as_uint(pr.ny);
+                                STG_U(threadIdx.x & 63u, 5) = __float_as_uint(pr.nz);
+                                STG_U(threadIdx.x & 63u, 6) = __float_as_uint(pr.e2);
+                            }
+                        }
+                        STG_U(threadIdx.x & 63u, 7) = flags;
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
                 uint32_t n_need = (uint32_t)__popcll(m_need);
                 uint32_t rank = lane_rank(m_need);
                 uint32_t n_take = n_need < chunk_left ? n_need : chunk_left;
                 if (phase == PH_OBJ && !has_ray && rank < n_take) {
-                    uint64_t item = chunk_base + (64u - chunk_left) + rank;
-                    Ray ray;
-                    uint64_t out_index;
-                    if (src.make(item, ray, out_index)) {
-                        has_ray = true;
-                        obj_i = 0;
-                        COLD(C_OX) = ray.o.x;
-                        COLD(C_OY) = ray.o.y;
-                        COLD(C_OZ) = ray.o.z;
-                        COLD(C_DX) = ray.d.x;
-                        COLD(C_DY) = ray.d.y;
-                        COLD(C_DZ) = ray.d.z;
-                        COLD(C_OUT) = __longlong_as_double((long long)out_index);
-                        COLD(C_BEST_T) = kInf;
-                        COLD(C_BEST_ID) = __longlong_as_double(-1ll);   // object = leaf = RTG_NONE
-                        ctr.nodes = 0;
-                        ctr.tris = 0;
+                    uint32_t slot = (64u - chunk_left) + rank;
+                    uint64_t item = chunk_base + slot;
+                    if (stage0) {
+                        uint32_t flags = STG_U(slot, 7);
+                        if (flags & 1u) {
+                            const DevObject &o0 = s.objects[0];
+                            has_ray = true;
+                            obj_i = 0;
+                            uint64_t out_index = src.slot_of(item);
+                            if (need_outer) {
+                                Ray ray;
+                                (void)src.make(item, ray, out_index);
+                                COLD(C_OX) = ray.o.x;
+                                COLD(C_OY) = ray.o.y;
+                                COLD(C_OZ) = ray.o.z;
+                                COLD(C_DX) = ray.d.x;
+                                COLD(C_DY) = ray.d.y;
+                                COLD(C_DZ) = ray.d.z;
+                            }
+                            COLD(C_OUT) = __longlong_as_double((long long)out_index);
+                            COLD(C_BEST_T) = kInf;
+                            COLD(C_BEST_ID) = __longlong_as_double(-1ll);   // object = leaf = RTG_NONE
+                            ctr.nodes = 0;
+                            ctr.tris = 0;
+                            // straight into the first object's tree
+                            in = Ray{mk(STG_D(slot, 0), STG_D(slot, 1), STG_D(slot, 2)),
+                                     mk(STG_D(slot, 3), STG_D(slot, 4), STG_D(slot, 5))};
+                            slab = (GBytePtr)o0.mesh.slab + sizeof(MeshSlabHeader);
+                            end = o0.mesh.n_nodes;
+                            cur = 0;
+                            h.has = false;
+                            h.t = kInf;
+                            h.leaf = RTG_NONE;
+                            if (!PRE) {
+                                fast = o0.mesh.fast_div_ok != 0 && fast_div_ray_ok(in);
+                                rcp = mk(1.0 / in.d.x, 1.0 / in.d.y, 1.0 / in.d.z);
+                            }
+                            if (PRE) {
+                                pre = (flags & 2u) != 0;
+                                r32x = __uint_as_float(STG_U(slot, 0));
+                                r32y = __uint_as_float(STG_U(slot, 1));
+                                r32z = __uint_as_float(STG_U(slot, 2));
+                                np32x = __uint_as_float(STG_U(slot, 3));
+                                np32y = __uint_as_float(STG_U(slot, 4));
+                                np32z = __uint_as_float(STG_U(slot, 5));
+                                e2 = __uint_as_float(STG_U(slot, 6));
+                                b32 = __builtin_inff();          // == (float)h.t: an empty holder keeps t = +inf
+                            }
+                            phase = PH_NODE;
+                        }
+                    } else {
+                        Ray ray;
+                        uint64_t out_index;
+                        if (src.make(item, ray, out_index)) {
+                            has_ray = true;
+                            obj_i = 0;
+                            COLD(C_OX) = ray.o.x;
+                            COLD(C_OY) = ray.o.y;
+                            COLD(C_OZ) = ray.o.z;
+                            COLD(C_DX) = ray.d.x;
+                            COLD(C_DY) = ray.d.y;
+                            COLD(C_DZ) = ray.d.z;
+                            COLD(C_OUT) = __longlong_as_double((long long)out_index);
+                            COLD(C_BEST_T) = kInf;
+                            COLD(C_BEST_ID) = __longlong_as_double(-1ll);   // object = leaf = RTG_NONE
+                            ctr.nodes = 0;
+                            ctr.tris = 0;
+                        }
                     }
                 }
                 chunk_left -= n_take;
@@ -429,26 +563,14 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     }
                     if (PRE) {
                         pre = o.mesh.f32_ok != 0 && pre_ray_ok(in);
-                        // q32 = fma(c32, r32, -(o32 * r32)) differs from the reference's f64 plane time (c - o) / d by at
-                        // most 2^-24 * (3|c| + 4|o|) * |r| (roundings of c, o, r to f32, of the product o32 * r32 and
-                        // of the fma); e2 = 16 * 2^-24 * (B + |o|) * |r| is twice what the difference of two such
-                        // times can be off by, and twice what a time minus the f32-rounded bound can be off by while
-                        // the bound is below 4 (B + |o|) |r| (above that the comparison is not close).  Axes with
-                        // d = 0 get r32 = NaN, so their plane times are NaN and drop out of the min/max as in the
-                        // f64 test.
-                        const float qnan = __builtin_nanf("");
-                        float o32x = (float)in.o.x, o32y = (float)in.o.y, o32z = (float)in.o.z;
-                        r32x = in.d.x == 0.0 ? qnan : (float)(1.0 / in.d.x);
-                        r32y = in.d.y == 0.0 ? qnan : (float)(1.0 / in.d.y);
-                        r32z = in.d.z == 0.0 ? qnan : (float)(1.0 / in.d.z);
-                        np32x = -(o32x * r32x);
-                        np32y = -(o32y * r32y);
-                        np32z = -(o32z * r32z);
-                        float b = o.mesh.coord_max;
-                        float ex = in.d.x == 0.0 ? 0.0f : (b + __builtin_fabsf(o32x)) * __builtin_fabsf(r32x);
-                        float ey = in.d.y == 0.0 ? 0.0f : (b + __builtin_fabsf(o32y)) * __builtin_fabsf(r32y);
-                        float ez = in.d.z == 0.0 ? 0.0f : (b + __builtin_fabsf(o32z)) * __builtin_fabsf(r32z);
-                        e2 = __builtin_fmaxf(ex, __builtin_fmaxf(ey, ez)) * 0x1p-20f;
+                        PreRay pr = make_pre_ray(in, o.mesh.coord_max);
+                        r32x = pr.rx;
+                        r32y = pr.ry;
+                        r32z = pr.rz;
+                        np32x = pr.nx;
+                        np32y = pr.ny;
+                        np32z = pr.nz;
+                        e2 = pr.e2;
                         b32 = __builtin_inff();          // == (float)h.t: an empty holder keeps t = +inf
                     }
                     phase = PH_NODE;
@@ -530,11 +652,9 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                         if (leaf_ref & 0x80000000u) {    // several leaves: the range lives in the full node
                             typedef const vu4 __attribute__((address_space(1))) *U4;
                             vu4 t = ((U4)node)[3];
-                            leaf_cur = t.z;
-                            leaf_end = t.z + t.w;
+                            leaf_cur = t.z | 0x80000000u;
                         } else {
                             leaf_cur = leaf_ref;
-                            leaf_end = leaf_ref + 1;
                         }
                         phase = PH_TRI;
                     }
@@ -557,23 +677,29 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
             }
             if (phase == PH_TRI) {
                 V3 v0, v1, v2;
-                load_tri_g((GTriPtr)(slab + (uint64_t)end * (sizeof(HotNode) + sizeof(DevNode))) + leaf_cur, v0, v1, v2);
+                const uint32_t leaf = leaf_cur & 0x7FFFFFFFu;
+                load_tri_g((GTriPtr)(slab + (uint64_t)end * (sizeof(HotNode) + sizeof(DevNode))) + leaf, v0, v1, v2);
                 double t;
                 bool some;
                 const MeshSlabHeader *hdr = (const MeshSlabHeader *)(const uint8_t *)(slab - sizeof(MeshSlabHeader));
                 if (PATCH && hdr->patches) {
                     PatchHit ph;
-                    some = patch_leaf_hit<false>(hdr->patches, hdr->leaf_info + leaf_cur, hdr->newton_steps, v0, v1, v2,
-                                                 in, ph);
+                    some = patch_leaf_hit<false>(hdr->patches, hdr->leaf_info + leaf, hdr->newton_steps, v0, v1, v2, in, ph);
                     t = ph.tau;
                 } else {
                     some = tri_hit_time_signs(v0, v1, v2, in, t);
                 }
-                holder_add(h, some, t, leaf_cur);
+                holder_add(h, some, t, leaf);
                 if (PRE) b32 = (float)h.t;       // an empty holder keeps t = +inf
                 if (COUNT) ctr.tris++;
+                bool more = false;
+                if (leaf_cur & 0x80000000u) {    // rare: the owning node (cur - 1) lists several leaves
+                    typedef const vu4 __attribute__((address_space(1))) *U4;
+                    vu4 tail = ((U4)((GNodePtr)(slab + (uint64_t)end * sizeof(HotNode)) + (cur - 1)))[3];
+                    more = leaf + 1 < tail.z + tail.w;
+                }
                 leaf_cur++;
-                if (leaf_cur >= leaf_end) phase = cur >= end ? PH_OBJ + 4 : PH_NODE;
+                if (!more) phase = cur >= end ? PH_OBJ + 4 : PH_NODE;
             }
             if (STATS) tk_tri += __builtin_amdgcn_s_memtime() - tk0;
         }
@@ -615,6 +741,8 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
 }
 
 #undef COLD
+#undef STG_D
+#undef STG_U
 
 // ---- self-test of div_by_const against the hardware division ----------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t &st) {
