@@ -39,6 +39,9 @@ namespace rtg {
 #endif
 enum : uint32_t { PH_IDLE = 0, PH_OBJ = 1, PH_NODE = 2, PH_TRI = 3 };
 
+// Lane mask of a predicate; the intrinsic folds into the compare that produced the predicate.
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // ---- ray sources ------------------------------------------------------------------
 struct PrimarySource {
     rtg_view view;
@@ -157,7 +160,7 @@ __device__ __forceinline__ bool tri_hit_time_signs(V3 v0, V3 v1, V3 v2, const Ra
     bool window = denom >= 0x1p-400 && denom <= 0x1p400 &&
                   (n0 == 0.0 || !(__builtin_fabs(n0) < tiny)) && (n1 == 0.0 || !(__builtin_fabs(n1) < tiny)) &&
                   (n2 == 0.0 || !(__builtin_fabs(n2) < tiny));
-    if (__ballot(!window) != 0) {
+    if (wave_ballot(!window) != 0) {
         ok = ok && !(n0 / denom < 0.0) && !(n1 / denom < 0.0) && !(n2 / denom < 0.0);
     } else {
         ok = ok && !(n0 < 0.0) && !(n1 < 0.0) && !(n2 < 0.0);
@@ -377,9 +380,9 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
 
     for (;;) {
         if (STATS) st_iter++;
-        uint64_t m_node = __ballot(phase == PH_NODE);
-        uint64_t m_tri = __ballot(phase == PH_TRI);
-        uint64_t m_obj = __ballot(phase == PH_OBJ);
+        uint64_t m_node = wave_ballot(phase == PH_NODE);
+        uint64_t m_tri = wave_ballot(phase == PH_TRI);
+        uint64_t m_obj = wave_ballot(phase == PH_OBJ);
         if ((m_node | m_tri | m_obj) == 0) break;   // every lane is done and no chunk is left
 
         // ---- between objects: finish the ray, fetch the next one, enter the next object -------
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 has_ray = false;
             }
             // (2) lanes without a ray take the next items of the wave's chunk
-            uint64_t m_need = __ballot(phase == PH_OBJ && !has_ray);
+            uint64_t m_need = wave_ballot(phase == PH_OBJ && !has_ray);
             while (m_need != 0 && !exhausted) {
                 if (STATS) st_refill++;
                 if (chunk_left == 0) {
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     }
                 }
                 chunk_left -= n_take;
-                m_need = __ballot(phase == PH_OBJ && !has_ray);
+                m_need = wave_ballot(phase == PH_OBJ && !has_ray);
             }
             if (exhausted && phase == PH_OBJ && !has_ray) phase = PH_IDLE;   // nothing left for this lane
             // (3) walk the object list up to the next mesh (spheres and planes are done in place)
@@ -587,8 +590,8 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 }
                 obj_i++;
             }
-            m_node = __ballot(phase == PH_NODE);
-            m_tri = __ballot(phase == PH_TRI);
+            m_node = wave_ballot(phase == PH_NODE);
+            m_tri = wave_ballot(phase == PH_TRI);
             if (STATS) tk_obj += __builtin_amdgcn_s_memtime() - tk0;
         }
 
@@ -599,8 +602,8 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 st_node_l += (uint32_t)__popcll(m_node);
                 tk0 = __builtin_amdgcn_s_memtime();
             }
-            bool slow_any = PRE || __ballot(phase == PH_NODE && !fast) != 0;
-            bool pre_all = PRE && __ballot(phase == PH_NODE && !pre) == 0;
+            bool slow_any = PRE || wave_ballot(phase == PH_NODE && !fast) != 0;
+            bool pre_all = PRE && wave_ballot(phase == PH_NODE && !pre) == 0;
             if (phase == PH_NODE) {
                 GNodePtr node = (GNodePtr)(slab + (uint64_t)end * sizeof(HotNode)) + cur;   // the full f64 node
                 bool go;
@@ -626,10 +629,10 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     bool yes = g1 > e2 && g2 > e2;
                     bool no = g1 < -e2 || g2 < -e2;
                     go = yes;
-                    if (__ballot(!(yes || no)) != 0) {
+                    if (wave_ballot(!(yes || no)) != 0) {
                         if (STATS) {
                             st_amb++;
-                            st_amb_l += (uint32_t)__popcll(__ballot(!(yes || no)));
+                            st_amb_l += (uint32_t)__popcll(wave_ballot(!(yes || no)));
                         }
                         if (!(yes || no)) {      // too close to call in single precision: the exact test decides
                             V3 lo, hi;
@@ -647,29 +650,27 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     skip = tail.x;
                     leaf_ref = tail.w == 0 ? 0xFFFFFFFFu : (tail.w == 1 ? tail.z : 0x80000000u);
                 }
-                if (go) {
-                    if (leaf_ref != 0xFFFFFFFFu) {
-                        if (leaf_ref & 0x80000000u) {    // several leaves: the range lives in the full node
-                            typedef const vu4 __attribute__((address_space(1))) *U4;
-                            vu4 t = ((U4)node)[3];
-                            leaf_cur = t.z | 0x80000000u;
-                        } else {
-                            leaf_cur = leaf_ref;
-                        }
-                        phase = PH_TRI;
+                // branch-free successor: a passed box goes on to the next array element, a failed one to the skip link
+                const bool to_leaf = go && leaf_ref != 0xFFFFFFFFu;
+                const uint32_t node_index = cur;
+                cur = go ? cur + 1 : skip;
+                leaf_cur = to_leaf ? leaf_ref : leaf_cur;
+                phase = to_leaf ? PH_TRI : PH_NODE;
+                if (wave_ballot(to_leaf && (leaf_ref & 0x80000000u)) != 0) {    // rare: a node with several leaves
+                    if (to_leaf && (leaf_ref & 0x80000000u)) {               // the range lives in the full node
+                        typedef const vu4 __attribute__((address_space(1))) *U4;
+                        vu4 t = ((U4)((GNodePtr)(slab + (uint64_t)end * sizeof(HotNode)) + node_index))[3];
+                        leaf_cur = t.z | 0x80000000u;
                     }
-                    cur = cur + 1;
-                } else {
-                    cur = skip;
                 }
                 if (phase == PH_NODE && cur >= end) phase = PH_OBJ + 4;   // traversal finished (resolved below)
             }
-            m_tri = __ballot(phase == PH_TRI);
+            m_tri = wave_ballot(phase == PH_TRI);
             if (STATS) tk_node += __builtin_amdgcn_s_memtime() - tk0;
         }
 
         // ---- one triangle per waiting lane ----------------------------------------------
-        if (m_tri != 0 && ((uint32_t)__popcll(m_tri) >= prm.tri_min || __ballot(phase == PH_NODE) == 0)) {
+        if (m_tri != 0 && ((uint32_t)__popcll(m_tri) >= prm.tri_min || wave_ballot(phase == PH_NODE) == 0)) {
             if (STATS) {
                 st_tri++;
                 st_tri_l += (uint32_t)__popcll(m_tri);
