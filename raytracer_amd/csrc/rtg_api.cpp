@@ -673,6 +673,10 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
     s->dev.overflow_stride = 1;
     s->dev.has_patches = 0;
     s->dev.any_f32_ok = 0;
+    s->dev.first_is_mesh = desc->n_objects != 0 && (desc->objects[0].kind == RTG_MESH || desc->objects[0].kind == RTG_PATCHES) &&
+                                   desc->objects[0].mesh->dev.n_nodes != 0
+                               ? 1u
+                               : 0u;
     for (uint32_t i = 0; i < desc->n_objects; i++) {
         const rtg_object &o = desc->objects[i];
         if (o.kind == RTG_PATCHES) s->dev.has_patches = 1;

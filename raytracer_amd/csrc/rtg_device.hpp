@@ -112,6 +112,7 @@ struct DevScene {
     uint32_t overflow_stride;    // threads the slab was sized for
     uint32_t has_patches;        // some object is a trispline patch set: launch the PATCH kernel variants
     uint32_t any_f32_ok;         // some mesh allows the single-precision box pre-test
+    uint32_t first_is_mesh;      // object 0 is a mesh or patch set with at least one node
 };
 
 // ------------------------------------------------------------------- math --

@@ -317,7 +317,9 @@ struct PhasedParams {
 };
 
 // STATS builds add per-wave step/lane tallies into work_counters[8*kCounterStride ...] (diagnostics only).
-template <class Source, bool COUNT, bool POINTS, bool PATCH, bool PRE, bool STATS = false>
+// FULL builds also fill rtg_point records and visit counters (whichever output is non-null); KEEP builds hold the
+// outer ray in LDS for later objects / point records (FULL implies KEEP).
+template <class Source, bool FULL, bool PATCH, bool PRE, bool KEEP, bool STATS = false>
 __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
                                                           uint32_t *work_counters, PhasedParams prm,
                                                           rtg_hit *out_hits, rtg_point *out_points,
@@ -341,9 +343,9 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
     bool has_ray = false;
     // Per-ray state that is only touched between objects lives in LDS ([field][lane], 8-byte fields, so a
     // wave's access is conflict-free): the outer ray, the output slot and the scene-level best hit.
-    __shared__ double cold[9 * kBlock];
+    extern __shared__ double cold[];      // 3 * kBlock doubles, or 9 * kBlock when prm.keep_outer
     double *cold_lane = cold + threadIdx.x;
-    enum { C_OX = 0, C_OY, C_OZ, C_DX, C_DY, C_DZ, C_BEST_T, C_BEST_ID, C_OUT };
+    enum { C_BEST_T = 0, C_BEST_ID, C_OUT, C_OX, C_OY, C_OZ, C_DX, C_DY, C_DZ };
 #define COLD(f) cold_lane[(f) * kBlock]
     // When the scene's first object is a mesh, a wave that takes a new 64-item chunk prepares all 64 rays at once
     // (ray generation, transform into the mesh's space, pre-test ray) with every lane busy and parks them here
@@ -352,12 +354,8 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
     __shared__ uint32_t stage_u[8 * kBlock];
 #define STG_D(slot, f) stage_d[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
 #define STG_U(slot, f) stage_u[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
-    bool stage0 = false;          // wave-uniform
-    if (s.n_objects != 0) {
-        const DevObject &o0 = s.objects[0];
-        stage0 = (o0.kind == RTG_MESH || o0.kind == RTG_PATCHES) && o0.mesh.n_nodes != 0;
-    }
-    const bool need_outer = POINTS || s.n_objects > 1;   // the outer ray is used again after the first object
+    const bool stage0 = !KEEP || s.first_is_mesh != 0;   // wave-uniform; builds without KEEP only run staged scenes
+    const bool need_outer = KEEP;
     Ray in{};                     // ray in the current object's space
     // Builds without the pre-test keep the reciprocal direction for the division-free f64 box test; builds with
     // it spend those registers on the f32 ray instead and use IEEE division wherever the pre-test cannot decide.
@@ -410,11 +408,11 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     v.w = (uint32_t)(tb >> 32);
                     *reinterpret_cast<uint4 *>(out_hits + out_index) = v;
                 }
-                if (POINTS) {
+                if (FULL && out_points) {
                     Ray ray{mk(COLD(C_OX), COLD(C_OY), COLD(C_OZ)), mk(COLD(C_DX), COLD(C_DY), COLD(C_DZ))};
                     scene_point<PATCH>(s, ray, sh, out_points[out_index]);
                 }
-                if (COUNT) {
+                if (FULL && out_counters) {
                     out_counters[out_index].nodes_visited = ctr.nodes;
                     out_counters[out_index].tris_tested = ctr.tris;
                 }
@@ -516,7 +514,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                             }
                             phase = PH_NODE;
                         }
-                    } else {
+                    } else if (KEEP) {
                         Ray ray;
                         uint64_t out_index;
                         if (src.make(item, ray, out_index)) {
@@ -541,7 +539,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
             }
             if (exhausted && phase == PH_OBJ && !has_ray) phase = PH_IDLE;   // nothing left for this lane
             // (3) walk the object list up to the next mesh (spheres and planes are done in place)
-            while (phase == PH_OBJ && has_ray && obj_i < s.n_objects) {
+            while (KEEP && phase == PH_OBJ && has_ray && obj_i < s.n_objects) {
                 const DevObject &o = s.objects[obj_i];
                 {
                     Ray ray{mk(COLD(C_OX), COLD(C_OY), COLD(C_OZ)), mk(COLD(C_DX), COLD(C_DY), COLD(C_DZ))};
@@ -618,7 +616,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     vf2 cz = {__uint_as_float(h1.x), __uint_as_float(h1.y)};
                     skip = h1.z;
                     leaf_ref = h1.w;
-                    if (COUNT) ctr.nodes++;
+                    if (FULL) ctr.nodes++;
                     vf2 qx = __builtin_elementwise_fma(cx, (vf2){r32x, r32x}, (vf2){np32x, np32x});
                     vf2 qy = __builtin_elementwise_fma(cy, (vf2){r32y, r32y}, (vf2){np32y, np32y});
                     vf2 qz = __builtin_elementwise_fma(cz, (vf2){r32z, r32z}, (vf2){np32z, np32z});
@@ -645,7 +643,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     V3 lo, hi;
                     uint4 tail;
                     load_node_g(node, lo, hi, tail);
-                    if (COUNT) ctr.nodes++;
+                    if (FULL) ctr.nodes++;
                     go = slow_any ? box_hit_div(lo, hi, in, h.t) : box_hit_fast(lo, hi, in, rcp, h.t);
                     skip = tail.x;
                     leaf_ref = tail.w == 0 ? 0xFFFFFFFFu : (tail.w == 1 ? tail.z : 0x80000000u);
@@ -692,7 +690,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 }
                 holder_add(h, some, t, leaf);
                 if (PRE) b32 = (float)h.t;       // an empty holder keeps t = +inf
-                if (COUNT) ctr.tris++;
+                if (FULL) ctr.tris++;
                 bool more = false;
                 if (leaf_cur & 0x80000000u) {    // rare: the owning node (cur - 1) lists several leaves
                     typedef const vu4 __attribute__((address_space(1))) *U4;
@@ -814,31 +812,37 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     uint64_t want = (chunks + 3) / 4;
     uint32_t grid = (uint32_t)(want < tune.max_blocks ? want : tune.max_blocks);
     if (grid == 0) grid = 1;
+    // the outer ray is needed after the first object when there are more objects, when point records are wanted,
+    // or when the first object is not a staged mesh; only then does the dynamic LDS hold it (9 cold fields per lane
+    // instead of 3)
+    const bool full = out_counters != nullptr || out_points != nullptr;
+    const bool keep = full || s.n_objects > 1 || !s.first_is_mesh;
+    const bool pre = tune.pretest && s.any_f32_ok;
     PhasedParams prm{tune.tri_min, tune.obj_min};
+    const size_t cold_bytes = (size_t)(keep ? 9 : 3) * kBlock * sizeof(double);
     dim3 g(grid), b(kBlock);
-    bool count = out_counters != nullptr, points = out_points != nullptr;
-#define RTG_L(C, P, X, S)                                                                                   \
-    do {                                                                                                    \
-        if (tune.pretest && s.any_f32_ok)                                                                   \
-            hipLaunchKernelGGL((k_trace_phased<Source, C, P, X, true, S>), g, b, 0, stream, s, src, n_items, \
-                               work_counters, prm, out_hits, out_points, out_counters);                     \
-        else                                                                                                \
-            hipLaunchKernelGGL((k_trace_phased<Source, C, P, X, false, S>), g, b, 0, stream, s, src, n_items, \
-                               work_counters, prm, out_hits, out_points, out_counters);                     \
+#define RTG_L(F, X, P, K, S)                                                                                      \
+    hipLaunchKernelGGL((k_trace_phased<Source, F, X, P, K, S>), g, b, cold_bytes, stream, s, src, n_items,       \
+                       work_counters, prm, out_hits, out_points, out_counters)
+#define RTG_L_PRE(F, X, K, S) \
+    do {                      \
+        if (pre)              \
+            RTG_L(F, X, true, K, S);  \
+        else                  \
+            RTG_L(F, X, false, K, S); \
     } while (0)
-    if (s.has_patches) {
-        if (count && points) RTG_L(true, true, true, false);
-        else if (count) RTG_L(true, false, true, false);
-        else if (points) RTG_L(false, true, true, false);
-        else RTG_L(false, false, true, false);
-    } else if (tune.stats && !count && !points) {
-        RTG_L(false, false, false, true);
+    if (tune.stats && !full && !keep && !s.has_patches) {
+        RTG_L_PRE(false, false, false, true);
+    } else if (s.has_patches) {
+        if (full) RTG_L_PRE(true, true, true, false);
+        else if (keep) RTG_L_PRE(false, true, true, false);
+        else RTG_L_PRE(false, true, false, false);
     } else {
-        if (count && points) RTG_L(true, true, false, false);
-        else if (count) RTG_L(true, false, false, false);
-        else if (points) RTG_L(false, true, false, false);
-        else RTG_L(false, false, false, false);
+        if (full) RTG_L_PRE(true, false, true, false);
+        else if (keep) RTG_L_PRE(false, false, true, false);
+        else RTG_L_PRE(false, false, false, false);
     }
+#undef RTG_L_PRE
 #undef RTG_L
     return hipGetLastError();
 }
