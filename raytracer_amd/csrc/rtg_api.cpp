@@ -387,6 +387,10 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) {
         ctx->tune.tri_min = (uint32_t)(value > 64 ? 64 : value);
         return RTG_OK;
     }
+    if (std::strcmp(key, "patch_tri_min") == 0) {
+        ctx->tune.patch_tri_min = (uint32_t)(value > 64 ? 64 : value);
+        return RTG_OK;
+    }
     if (std::strcmp(key, "obj_min") == 0) {
         ctx->tune.obj_min = (uint32_t)(value > 64 ? 64 : value);
         return RTG_OK;

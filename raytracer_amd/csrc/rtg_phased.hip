@@ -818,7 +818,7 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     const bool full = out_counters != nullptr || out_points != nullptr;
     const bool keep = full || s.n_objects > 1 || !s.first_is_mesh;
     const bool pre = tune.pretest && s.any_f32_ok;
-    PhasedParams prm{tune.tri_min, tune.obj_min};
+    PhasedParams prm{s.has_patches ? tune.patch_tri_min : tune.tri_min, tune.obj_min};
     const size_t cold_bytes = (size_t)(keep ? 9 : 3) * kBlock * sizeof(double);
     dim3 g(grid), b(kBlock);
 #define RTG_L(F, X, P, K, S)                                                                                      \

@@ -11,6 +11,9 @@ W, H = 3840, 2160
 patches = rtg.patch_terrain(125, 62, seed=7, scale=100.0)
 t0 = time.time(); pm = rtg.HostPatchMesh(patches, k=8, newton_steps=5); print(f"patches {len(patches)} facets {pm.bvh.n_leaves} build {time.time()-t0:.1f}s depth {pm.bvh.depth}", flush=True)
 ctx = rtg.Context(0)
+for kv in sys.argv[1:]:                       # ctx options, e.g. tri_min=24
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); ctx.set_stream(stream.cuda_stream)
 mesh = ctx.mesh(pm)
 scene = ctx.scene([rtg.patch_object(mesh, rtg.material((1, 1, 1)), rtg.transform(0.01))])
