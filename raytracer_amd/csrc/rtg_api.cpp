@@ -55,6 +55,7 @@ struct rtg_scene {
     DevScene dev{};
     void *d_objects = nullptr;
     uint32_t max_depth = 0;
+    bool any_dielectric = false;   // some material refracts: frames need the specular path tree
 };
 
 namespace {
@@ -675,6 +676,8 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
     s->dev.overflow = nullptr;
     s->dev.overflow_levels = 0;
     s->dev.overflow_stride = 1;
+    for (uint32_t i = 0; i < desc->n_objects; i++)
+        if (desc->objects[i].material.has_dielectric || desc->objects[i].material2.has_dielectric) s->any_dielectric = true;
     s->dev.has_patches = 0;
     s->dev.any_f32_ok = 0;
     s->dev.first_is_mesh = desc->n_objects != 0 && (desc->objects[0].kind == RTG_MESH || desc->objects[0].kind == RTG_PATCHES) &&
@@ -769,6 +772,26 @@ int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *o
     return RTG_OK;
 }
 
+namespace {
+// compute_direct_irrad for device-resident points through the persistent kernel: one closest-hit launch over all
+// (light, point) shadow rays, then one resolve pass.
+int shade_wavefront(rtg_ctx *ctx, const DevScene &ds, const rtg_light *d_lights, uint32_t n_lights,
+                    const rtg_point *d_points, uint64_t n_points, double *d_rgb, uint8_t *d_rgba8) {
+    int rc;
+    void *occ = nullptr;
+    if (n_lights != 0) {
+        void *wc = nullptr;
+        if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
+        if ((rc = scratch_get(ctx, "occluders", (size_t)n_lights * n_points * sizeof(rtg_hit), &occ)) != RTG_OK) return rc;
+        HIP_TRY(ctx, launch_shadow_phased(ctx->stream, ds, d_points, n_points, d_lights, n_lights, (uint32_t *)wc,
+                                          ctx->tune, (rtg_hit *)occ));
+    }
+    HIP_TRY(ctx, launch_shade_resolve(ctx->stream, ds, d_lights, n_lights, d_points, n_points, (const rtg_hit *)occ,
+                                      d_rgb, d_rgba8));
+    return RTG_OK;
+}
+} // namespace
+
 int rtg_shade_direct(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const rtg_point *points,
                      uint64_t n_points, double *rgb_out, uint8_t *rgba8_out) {
     int rc = check_scene_call(scene);
@@ -778,7 +801,8 @@ int rtg_shade_direct(rtg_scene *scene, const rtg_light *lights, uint32_t n_light
     if (!points) return fail(ctx, RTG_E_INVALID, "rtg_shade_direct: points is null");
     if (n_lights && !lights) return fail(ctx, RTG_E_INVALID, "rtg_shade_direct: lights is null");
     if (!rgb_out && !rgba8_out) return fail(ctx, RTG_E_INVALID, "rtg_shade_direct: no output requested");
-    if (n_points > (0x7FFFFFFFull * kBlock)) return fail(ctx, RTG_E_LIMIT, "rtg_shade_direct: too many points for one launch");
+    if (n_points > (0x7FFFFFFFull * kBlock) || (n_lights != 0 && n_points > (1ull << 37) / n_lights))
+        return fail(ctx, RTG_E_LIMIT, "rtg_shade_direct: too many points for one launch");
     const void *d_lights = nullptr, *d_points = nullptr;
     if ((rc = in_prepare(ctx, "in_lights", lights, (size_t)n_lights * sizeof(rtg_light), &d_lights)) != RTG_OK) return rc;
     if ((rc = in_prepare(ctx, "in_points", points, n_points * sizeof(rtg_point), &d_points)) != RTG_OK) return rc;
@@ -788,8 +812,14 @@ int rtg_shade_direct(rtg_scene *scene, const rtg_light *lights, uint32_t n_light
     DevScene ds;
     uint64_t threads = (n_points + kBlock - 1) / kBlock * kBlock;
     if ((rc = scene_for_launch(scene, threads, ds)) != RTG_OK) return rc;
-    HIP_TRY(ctx, launch_shade_direct(ctx->stream, ds, (const rtg_light *)d_lights, n_lights, (const rtg_point *)d_points,
-                                     n_points, (double *)orgb.dev, (uint8_t *)o8.dev));
+    if (ctx->traversal == 2) {
+        if ((rc = shade_wavefront(ctx, ds, (const rtg_light *)d_lights, n_lights, (const rtg_point *)d_points, n_points,
+                                  (double *)orgb.dev, (uint8_t *)o8.dev)) != RTG_OK)
+            return rc;
+    } else {
+        HIP_TRY(ctx, launch_shade_direct(ctx->stream, ds, (const rtg_light *)d_lights, n_lights,
+                                         (const rtg_point *)d_points, n_points, (double *)orgb.dev, (uint8_t *)o8.dev));
+    }
     if ((rc = out_finish(ctx, orgb)) != RTG_OK) return rc;
     if ((rc = out_finish(ctx, o8)) != RTG_OK) return rc;
     if (orgb.staged || o8.staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -821,8 +851,22 @@ int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *li
     if ((rc = out_prepare(ctx, "out_hits", out_hits, n * sizeof(rtg_hit), oh)) != RTG_OK) return rc;
     DevScene ds;
     if ((rc = scene_for_launch(scene, tiles * kBlock, ds)) != RTG_OK) return rc;
-    HIP_TRY(ctx, launch_render_frame(ctx->stream, ds, *view, (const rtg_light *)d_lights, n_lights, width, height, tile,
-                                     max_depth, (double *)orgb.dev, (uint8_t *)o8.dev, (rtg_hit *)oh.dev));
+    if (ctx->traversal == 2 && max_depth >= 1 && !scene->any_dielectric && n_lights <= (1ull << 37) / n) {
+        // no refracting material: every pixel is one primary hit plus its shadow rays, so the frame is three passes
+        // of the persistent kernel's building blocks (primary hits with point records, shadow rays, resolve)
+        void *wc = nullptr, *pts = nullptr;
+        if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
+        if ((rc = scratch_get(ctx, "frame_points", n * sizeof(rtg_point), &pts)) != RTG_OK) return rc;
+        HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, (uint32_t *)wc, ctx->tune,
+                                                  (rtg_hit *)oh.dev, (rtg_point *)pts, nullptr));
+        if (orgb.dev || o8.dev)
+            if ((rc = shade_wavefront(ctx, ds, (const rtg_light *)d_lights, n_lights, (const rtg_point *)pts, n,
+                                      (double *)orgb.dev, (uint8_t *)o8.dev)) != RTG_OK)
+                return rc;
+    } else {
+        HIP_TRY(ctx, launch_render_frame(ctx->stream, ds, *view, (const rtg_light *)d_lights, n_lights, width, height,
+                                         tile, max_depth, (double *)orgb.dev, (uint8_t *)o8.dev, (rtg_hit *)oh.dev));
+    }
     if ((rc = out_finish(ctx, orgb)) != RTG_OK) return rc;
     if ((rc = out_finish(ctx, o8)) != RTG_OK) return rc;
     if ((rc = out_finish(ctx, oh)) != RTG_OK) return rc;

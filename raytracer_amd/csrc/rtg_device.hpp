@@ -773,6 +773,30 @@ __device__ __forceinline__ Ray primary_ray(const rtg_view &v, uint32_t x, uint32
 }
 
 // --------------------------------------------------------------- shading --
+// One light of compute_direct_irrad (render/renderer.rs:184-205) up to its shadow ray: the displacement to the
+// light, the Lambert cosine against the interpolated normal, and the bounce ray whose closest hit decides
+// occlusion.  Returns false when the light is behind the surface (no query is made then).
+struct ShadowQuery {
+    Ray ray;
+    double dis, dis2, d;
+};
+__device__ __forceinline__ bool shadow_query(const rtg_light &light, V3 position, V3 inter_normal, ShadowQuery &q) {
+    V3 disp = ld3(light.position) - position;
+    q.dis2 = dot(disp, disp);
+    q.dis = __builtin_sqrt(q.dis2);
+    V3 dir = disp / q.dis;
+    q.d = dot(dir, inter_normal);
+    if (q.d < 0.0) return false;
+    q.ray = new_bounce(position, dir);
+    return true;
+}
+// The light's contribution once the occluder (closest hit along the shadow ray) is known.
+__device__ __forceinline__ V3 add_light(V3 lighting, const rtg_light &light, const ShadowQuery &q, bool occ_have,
+                                        double occ_t) {
+    if (occ_have && occ_t < q.dis) return lighting;
+    return lighting + (ld3(light.color) * q.d) / (4.0 * kPi * q.dis2);
+}
+
 // compute_direct_irrad (render/renderer.rs:184-205): one closest-hit shadow
 // query per light, Lambert term over 4*pi*dis^2.
 template <bool COUNT, bool PATCH>
@@ -780,18 +804,10 @@ __device__ __forceinline__ V3 direct_irrad(const DevScene &s, const rtg_light *l
                                            V3 position, V3 inter_normal, const TraceCtx &tc, Counter &ctr) {
     V3 lighting = mk(1.0, 1.0, 1.0) * 0.0;
     for (uint32_t i = 0; i < n_lights; i++) {
-        V3 lp = ld3(lights[i].position);
-        V3 color = ld3(lights[i].color);
-        V3 disp = lp - position;
-        double dis2 = dot(disp, disp);
-        double dis = __builtin_sqrt(dis2);
-        V3 dir = disp / dis;
-        double d = dot(dir, inter_normal);
-        if (d < 0.0) continue;
-        Ray ray = new_bounce(position, dir);
-        SceneHit occ = scene_closest<COUNT, PATCH>(s, ray, tc, ctr);
-        if (occ.have && occ.t < dis) continue;
-        lighting = lighting + (color * d) / (4.0 * kPi * dis2);
+        ShadowQuery q;
+        if (!shadow_query(lights[i], position, inter_normal, q)) continue;
+        SceneHit occ = scene_closest<COUNT, PATCH>(s, q.ray, tc, ctr);
+        lighting = add_light(lighting, lights[i], q, occ.have, occ.t);
     }
     return lighting;
 }

@@ -123,6 +123,46 @@ __global__ __launch_bounds__(kBlock) void k_shade_direct(DevScene s, const rtg_l
     }
 }
 
+// The same shading with the shadow queries already answered (one closest hit per light and point, found by the
+// persistent kernel): occluders[l * n + p].  Pairs without a query were never written and are never read.
+__global__ __launch_bounds__(kBlock) void k_shade_resolve(DevScene s, const rtg_light *__restrict__ lights,
+                                                           uint32_t n_lights, const rtg_point *__restrict__ points,
+                                                           uint64_t n, const rtg_hit *__restrict__ occluders,
+                                                           double *rgb_out, uint8_t *rgba8_out) {
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= n) return;
+    const rtg_point &pt = points[gid];
+    V3 total = mk(0.0, 0.0, 0.0);
+    if (pt.manifold_len != 0) {
+        V3 position = ld3(pt.position), inter_normal = ld3(pt.inter_normal);
+        V3 lighting = mk(1.0, 1.0, 1.0) * 0.0;
+        for (uint32_t i = 0; i < n_lights; i++) {
+            ShadowQuery q;
+            if (!shadow_query(lights[i], position, inter_normal, q)) continue;
+            uint4 o = *reinterpret_cast<const uint4 *>(occluders + (uint64_t)i * n + gid);
+            double occ_t = __longlong_as_double((long long)(((uint64_t)o.w << 32) | o.z));
+            lighting = add_light(lighting, lights[i], q, o.x != RTG_NONE, occ_t);
+        }
+        V3 irrad = (mk(0.0, 0.0, 0.0) + lighting) + mk(0.0, 0.0, 0.0);
+        const DevMaterial &m = material_of_slot(s, pt.material_slot);
+        V3 dm = mk(irrad.x * m.diffuse[0], irrad.y * m.diffuse[1], irrad.z * m.diffuse[2]);
+        total = total + dm * 1.0;
+    }
+    if (rgb_out) {
+        rgb_out[gid * 3 + 0] = total.x;
+        rgb_out[gid * 3 + 1] = total.y;
+        rgb_out[gid * 3 + 2] = total.z;
+    }
+    if (rgba8_out) {
+        uchar4 c;
+        c.x = pq8(total.x);
+        c.y = pq8(total.y);
+        c.z = pq8(total.z);
+        c.w = 255;
+        reinterpret_cast<uchar4 *>(rgba8_out)[gid] = c;
+    }
+}
+
 // Dielectric::new (render/dielectric.rs:13-52).
 struct Dielectric {
     double reflectance;
@@ -326,6 +366,16 @@ hipError_t launch_shade_direct(hipStream_t stream, const DevScene &s, const rtg_
         hipLaunchKernelGGL(k_shade_direct<true>, grid, block, 0, stream, s, lights, n_lights, points, n, rgb_out, rgba8_out);
     else
         hipLaunchKernelGGL(k_shade_direct<false>, grid, block, 0, stream, s, lights, n_lights, points, n, rgb_out, rgba8_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_shade_resolve(hipStream_t stream, const DevScene &s, const rtg_light *lights, uint32_t n_lights,
+                                const rtg_point *points, uint64_t n, const rtg_hit *occluders, double *rgb_out,
+                                uint8_t *rgba8_out) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((uint32_t)((n + kBlock - 1) / kBlock)), block(kBlock);
+    hipLaunchKernelGGL(k_shade_resolve, grid, block, 0, stream, s, lights, n_lights, points, n, occluders, rgb_out,
+                       rgba8_out);
     return hipGetLastError();
 }
 

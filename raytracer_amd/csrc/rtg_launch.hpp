@@ -34,6 +34,15 @@ hipError_t launch_trace_phased(hipStream_t stream, const DevScene &s, const doub
                                uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits,
                                rtg_point *out_points, rtg_ray_counters *out_counters);
 
+// Closest hit along the shadow ray of every (light, point) pair that has one; out_occluders[l * n_points + p].
+hipError_t launch_shadow_phased(hipStream_t stream, const DevScene &s, const rtg_point *points, uint64_t n_points,
+                                const rtg_light *lights, uint32_t n_lights, uint32_t *work_counters,
+                                const PhasedTuning &tune, rtg_hit *out_occluders);
+// compute_direct_irrad x diffuse from occluders found by launch_shadow_phased.
+hipError_t launch_shade_resolve(hipStream_t stream, const DevScene &s, const rtg_light *lights, uint32_t n_lights,
+                                const rtg_point *points, uint64_t n, const rtg_hit *occluders, double *rgb_out,
+                                uint8_t *rgba8_out);
+
 hipError_t launch_selftest_div(hipStream_t stream, uint64_t seed, uint32_t blocks, uint32_t per_thread, uint32_t family,
                                uint64_t *out3);
 

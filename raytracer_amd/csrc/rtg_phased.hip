@@ -86,6 +86,28 @@ struct BatchSource {
     }
 };
 
+// Shadow rays of compute_direct_irrad (render/renderer.rs:184-205) for a batch of surface points: item
+// l * n_points + p is light l seen from point p; items without a query (no hit at p, light behind the surface)
+// produce no ray and leave their output slot untouched.
+struct ShadowSource {
+    const rtg_point *points;
+    const rtg_light *lights;
+    uint64_t n_points;
+    uint32_t n_lights;
+    __device__ __forceinline__ uint64_t slot_of(uint64_t item) const { return item; }
+    __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
+        uint64_t l = item / n_points, p = item - l * n_points;
+        if (l >= n_lights) return false;
+        const rtg_point &pt = points[p];
+        if (pt.manifold_len == 0) return false;
+        ShadowQuery q;
+        if (!shadow_query(lights[l], ld3(pt.position), ld3(pt.inter_normal), q)) return false;
+        ray = q.ray;
+        out_index = item;
+        return true;
+    }
+};
+
 // ---- exact division by a per-ray constant ------------------------------------------
 __device__ __forceinline__ double div_by_const(double x, double d, double r) {
     double q0 = x * r;
@@ -868,6 +890,17 @@ hipError_t launch_trace_phased(hipStream_t stream, const DevScene &s, const doub
     src.rays6 = rays6;
     src.n = n;
     return launch_phased(stream, s, src, n, work_counters, tune, out_hits, out_points, out_counters);
+}
+
+hipError_t launch_shadow_phased(hipStream_t stream, const DevScene &s, const rtg_point *points, uint64_t n_points,
+                                const rtg_light *lights, uint32_t n_lights, uint32_t *work_counters,
+                                const PhasedTuning &tune, rtg_hit *out_occluders) {
+    ShadowSource src;
+    src.points = points;
+    src.lights = lights;
+    src.n_points = n_points;
+    src.n_lights = n_lights;
+    return launch_phased(stream, s, src, n_points * n_lights, work_counters, tune, out_occluders, nullptr, nullptr);
 }
 
 } // namespace rtg

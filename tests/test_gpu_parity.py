@@ -290,6 +290,41 @@ def test_fused_frame_mesh_scene_and_cpp_renderer(gpu_ctx):
     assert hdr.startswith(b"#?RADIANCE\n") and len(hdr) > 120 * 80 * 4
 
 
+@pytest.mark.parametrize("traversal", TRAVERSALS)
+def test_frame_of_opaque_scene_in_passes(gpu_ctx, traversal):
+    """Scenes without a refracting material: the default traversal renders the frame as passes of the persistent
+    kernel (primary hits with point records, one shadow-ray batch over all lights, resolve); the other traversals use
+    the fused kernel.  All must equal the oracle, on full frames, on a ragged tile and with no light at all."""
+    gpu_ctx.set_option("traversal", traversal)
+    tris, xform = scenes.terrain(80, 80, seed=9)
+    vn = scenes.vertex_normals_for(tris)
+    bvh = rtg.HostBvh(tris, vertex_normals=vn)
+    _, lights, view = scenes.default_objects(17)
+    plane = rtg.plane_object((0, -0.5, 0), (0, 0, -1), (-1, 0, 0), rtg.material((1.0, 1.0, 1.0)), rtg.material((0.1, 0.1, 0.1)))
+    ball = rtg.sphere_object((0.3, -0.1, -0.4), 0.15, rtg.material((0.9, 0.2, 0.2)))
+    mesh = rtg.mesh_object(None, rtg.material((0.8, 0.7, 0.6)), xform)
+    for objs, meshes in (([mesh], {0: bvh}), ([plane, ball, mesh], {2: bvh})):
+        pair = scenes.Pair(gpu_ctx, objs, meshes)
+        w, h = 200, 120
+        for tile, use_lights in ((None, lights), ((13, 7, 150, 90), lights), (None, lights[:0])):
+            g_rgb, g_c8, g_hits = pair.gpu.render_frame(view, use_lights, w, h, tile=tile, max_depth=4)
+            c_rgb, c_c8, c_hits = pair.cpu.render_frame(view, use_lights, w, h, tile=tile, max_depth=4)
+            _assert_hits_equal(g_hits, c_hits)
+            assert not scenes.float_bits_differ(g_rgb, c_rgb).any()
+            assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1
+            if len(use_lights):
+                assert (g_rgb.sum(axis=1) > 0).mean() > 0.2
+            else:
+                assert (g_rgb == 0).all()
+        # shading of already-built points goes through the same passes
+        _, g_pts, _ = pair.gpu.render_primary(view, w, h, points=True)
+        g_rgb, g_c8 = pair.gpu.shade_direct(lights, g_pts, rgba8=True)
+        c_rgb, c_c8 = pair.cpu.shade_direct(lights, g_pts, rgba8=True)
+        assert not scenes.float_bits_differ(g_rgb, c_rgb).any()
+        assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1
+    gpu_ctx.set_option("traversal", 2)
+
+
 def test_device_f64_div_and_sqrt_are_correctly_rounded(gpu_ctx):
     """The parity argument rests on IEEE-exact device / and sqrt: sweep them through the ray normalisation."""
     import math
