@@ -78,6 +78,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
+    torch.cuda.set_device(local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -87,7 +88,6 @@ def main():
     if args.gpus != world:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     nx, ny = GRID if args.grid is None else tuple(int(v) for v in args.grid.lower().split("x"))
@@ -168,7 +168,7 @@ def main():
         mrays = args.steps * world * n_rays / elapsed / 1e6
 
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:          # the CPU leg is reported for the single-GPU line only
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import orc
             cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
