@@ -98,6 +98,11 @@ def main():
     ctx = rtg.Context(local_rank)
     if args.traversal >= 0:
         ctx.set_option("traversal", args.traversal)
+    if use_dist:
+        # The persistent kernel fills every block slot of the GPU for the whole frame (128 VGPRs x 4 waves per
+        # SIMD), so a gather kernel on the second stream could only start when a frame drains.  Leaving 32 of the
+        # 1024 slots free lets RCCL's send/recv blocks run next to the traversal of the following frame.
+        ctx.set_option("max_blocks", 992)
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
