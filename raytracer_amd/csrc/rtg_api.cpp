@@ -721,10 +721,14 @@ int rtg_render_primary(rtg_scene *scene, const rtg_view *view, uint32_t width, u
     DevScene ds;
     if ((rc = scene_for_launch(scene, tiles * kBlock, ds)) != RTG_OK) return rc;
     if (ctx->traversal == 2) {
-        void *wc = nullptr;
+        void *wc = nullptr, *hits = oh.dev;
         if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
+        if (op.dev && !hits && (rc = scratch_get(ctx, "points_hits", n * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
         HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, (uint32_t *)wc, ctx->tune,
-                                                  (rtg_hit *)oh.dev, (rtg_point *)op.dev, (rtg_ray_counters *)oc.dev));
+                                                  (rtg_hit *)hits, (rtg_ray_counters *)oc.dev));
+        if (op.dev)
+            HIP_TRY(ctx, launch_points_primary(ctx->stream, ds, *view, width, height, tile, (const rtg_hit *)hits,
+                                               (rtg_point *)op.dev));
     } else {
         HIP_TRY(ctx, launch_render_primary(ctx->stream, ds, *view, width, height, tile, (rtg_hit *)oh.dev,
                                            (rtg_point *)op.dev, (rtg_ray_counters *)oc.dev));
@@ -757,10 +761,14 @@ int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *o
     uint64_t threads = (n_rays + kBlock - 1) / kBlock * kBlock;
     if ((rc = scene_for_launch(scene, threads, ds)) != RTG_OK) return rc;
     if (ctx->traversal == 2) {
-        void *wc = nullptr;
+        void *wc = nullptr, *hits = oh.dev;
         if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
+        if (op.dev && !hits && (rc = scratch_get(ctx, "points_hits", n_rays * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
         HIP_TRY(ctx, launch_trace_phased(ctx->stream, ds, (const double *)d_rays, n_rays, (uint32_t *)wc, ctx->tune,
-                                         (rtg_hit *)oh.dev, (rtg_point *)op.dev, (rtg_ray_counters *)oc.dev));
+                                         (rtg_hit *)hits, (rtg_ray_counters *)oc.dev));
+        if (op.dev)
+            HIP_TRY(ctx, launch_points_batch(ctx->stream, ds, (const double *)d_rays, n_rays, (const rtg_hit *)hits,
+                                             (rtg_point *)op.dev));
     } else {
         HIP_TRY(ctx, launch_trace(ctx->stream, ds, (const double *)d_rays, n_rays, (rtg_hit *)oh.dev,
                                   (rtg_point *)op.dev, (rtg_ray_counters *)oc.dev));
@@ -857,8 +865,13 @@ int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *li
         void *wc = nullptr, *pts = nullptr;
         if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
         if ((rc = scratch_get(ctx, "frame_points", n * sizeof(rtg_point), &pts)) != RTG_OK) return rc;
+        void *hits = oh.dev;
+        if (!hits && (rc = scratch_get(ctx, "points_hits", n * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
         HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, (uint32_t *)wc, ctx->tune,
-                                                  (rtg_hit *)oh.dev, (rtg_point *)pts, nullptr));
+                                                  (rtg_hit *)hits, nullptr));
+        if (orgb.dev || o8.dev)
+            HIP_TRY(ctx, launch_points_primary(ctx->stream, ds, *view, width, height, tile, (const rtg_hit *)hits,
+                                               (rtg_point *)pts));
         if (orgb.dev || o8.dev)
             if ((rc = shade_wavefront(ctx, ds, (const rtg_light *)d_lights, n_lights, (const rtg_point *)pts, n,
                                       (double *)orgb.dev, (uint8_t *)o8.dev)) != RTG_OK)

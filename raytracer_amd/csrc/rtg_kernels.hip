@@ -88,6 +88,41 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const double *__re
     }
 }
 
+// RaycastPoint records for hits that are already known (the persistent kernel reports ids and times only): the
+// winner's point is a function of the ray and the hit, so it is rebuilt here with every lane busy.
+__device__ __forceinline__ Ray load_ray(const double *rays6, uint64_t i) {
+    // 48 B per ray, 16-B aligned: three 128-bit loads
+    const double2 *q = reinterpret_cast<const double2 *>(rays6 + i * 6);
+    double2 a = q[0], b = q[1], c = q[2];
+    return Ray{mk(a.x, a.y, b.x), mk(b.y, c.x, c.y)};
+}
+__device__ __forceinline__ SceneHit load_hit(const rtg_hit *p) {
+    uint4 v = *reinterpret_cast<const uint4 *>(p);
+    SceneHit h;
+    h.object = v.x;
+    h.leaf = v.y;
+    h.t = __longlong_as_double((long long)(((uint64_t)v.w << 32) | v.z));
+    h.have = v.x != RTG_NONE;
+    return h;
+}
+template <bool PATCH>
+__global__ __launch_bounds__(kBlock) void k_points_primary(DevScene s, rtg_view view, uint32_t width, uint32_t height,
+                                                            rtg_rect tile, const rtg_hit *__restrict__ hits,
+                                                            rtg_point *out_points) {
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (uint64_t)tile.w * tile.h) return;
+    uint32_t py = (uint32_t)(gid / tile.w), px = (uint32_t)(gid - (uint64_t)py * tile.w);
+    Ray ray = primary_ray(view, tile.x0 + px, tile.y0 + py, width, height);
+    scene_point<PATCH>(s, ray, load_hit(hits + gid), out_points[gid]);
+}
+template <bool PATCH>
+__global__ __launch_bounds__(kBlock) void k_points_batch(DevScene s, const double *__restrict__ rays6, uint64_t n,
+                                                          const rtg_hit *__restrict__ hits, rtg_point *out_points) {
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= n) return;
+    scene_point<PATCH>(s, load_ray(rays6, gid), load_hit(hits + gid), out_points[gid]);
+}
+
 // compute_direct_irrad x diffuse for already-built points (renderer.rs:184-205,270-277).
 template <bool PATCH>
 __global__ __launch_bounds__(kBlock) void k_shade_direct(DevScene s, const rtg_light *__restrict__ lights,
@@ -366,6 +401,29 @@ hipError_t launch_shade_direct(hipStream_t stream, const DevScene &s, const rtg_
         hipLaunchKernelGGL(k_shade_direct<true>, grid, block, 0, stream, s, lights, n_lights, points, n, rgb_out, rgba8_out);
     else
         hipLaunchKernelGGL(k_shade_direct<false>, grid, block, 0, stream, s, lights, n_lights, points, n, rgb_out, rgba8_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_points_primary(hipStream_t stream, const DevScene &s, const rtg_view &view, uint32_t width,
+                                 uint32_t height, rtg_rect tile, const rtg_hit *hits, rtg_point *out_points) {
+    uint64_t n = (uint64_t)tile.w * tile.h;
+    if (n == 0) return hipSuccess;
+    dim3 grid((uint32_t)((n + kBlock - 1) / kBlock)), block(kBlock);
+    if (s.has_patches)
+        hipLaunchKernelGGL(k_points_primary<true>, grid, block, 0, stream, s, view, width, height, tile, hits, out_points);
+    else
+        hipLaunchKernelGGL(k_points_primary<false>, grid, block, 0, stream, s, view, width, height, tile, hits, out_points);
+    return hipGetLastError();
+}
+
+hipError_t launch_points_batch(hipStream_t stream, const DevScene &s, const double *rays6, uint64_t n,
+                               const rtg_hit *hits, rtg_point *out_points) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((uint32_t)((n + kBlock - 1) / kBlock)), block(kBlock);
+    if (s.has_patches)
+        hipLaunchKernelGGL(k_points_batch<true>, grid, block, 0, stream, s, rays6, n, hits, out_points);
+    else
+        hipLaunchKernelGGL(k_points_batch<false>, grid, block, 0, stream, s, rays6, n, hits, out_points);
     return hipGetLastError();
 }
 

@@ -28,11 +28,16 @@ struct PhasedTuning {
 };
 hipError_t launch_render_primary_phased(hipStream_t stream, const DevScene &s, const rtg_view &view, uint32_t width,
                                         uint32_t height, rtg_rect tile, uint32_t *work_counters,
-                                        const PhasedTuning &tune, rtg_hit *out_hits, rtg_point *out_points,
-                                        rtg_ray_counters *out_counters);
+                                        const PhasedTuning &tune, rtg_hit *out_hits, rtg_ray_counters *out_counters);
 hipError_t launch_trace_phased(hipStream_t stream, const DevScene &s, const double *rays6, uint64_t n,
                                uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits,
-                               rtg_point *out_points, rtg_ray_counters *out_counters);
+                               rtg_ray_counters *out_counters);
+// RaycastPoint records rebuilt from hit ids (one lane per ray, streaming): the rays are regenerated from the view
+// or read from the batch.
+hipError_t launch_points_primary(hipStream_t stream, const DevScene &s, const rtg_view &view, uint32_t width,
+                                 uint32_t height, rtg_rect tile, const rtg_hit *hits, rtg_point *out_points);
+hipError_t launch_points_batch(hipStream_t stream, const DevScene &s, const double *rays6, uint64_t n,
+                               const rtg_hit *hits, rtg_point *out_points);
 
 // Closest hit along the shadow ray of every (light, point) pair that has one; out_occluders[l * n_points + p].
 hipError_t launch_shadow_phased(hipStream_t stream, const DevScene &s, const rtg_point *points, uint64_t n_points,

@@ -339,13 +339,13 @@ struct PhasedParams {
 };
 
 // STATS builds add per-wave step/lane tallies into work_counters[8*kCounterStride ...] (diagnostics only).
-// FULL builds also fill rtg_point records and visit counters (whichever output is non-null); KEEP builds hold the
-// outer ray in LDS for later objects / point records (FULL implies KEEP).
-template <class Source, bool FULL, bool PATCH, bool PRE, bool KEEP, bool STATS = false>
+// COUNT builds tally node visits and triangle tests per ray; KEEP builds hold the outer ray in LDS for the objects
+// after the first.  Point records are not built here: a streaming pass rebuilds them from the hit ids
+// (k_points_primary / k_points_batch), with every lane busy.
+template <class Source, bool COUNT, bool PATCH, bool PRE, bool KEEP, bool STATS = false>
 __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
                                                           uint32_t *work_counters, PhasedParams prm,
-                                                          rtg_hit *out_hits, rtg_point *out_points,
-                                                          rtg_ray_counters *out_counters) {
+                                                          rtg_hit *out_hits, rtg_ray_counters *out_counters) {
     uint32_t st_iter = 0, st_node = 0, st_node_l = 0, st_tri = 0, st_tri_l = 0, st_obj = 0, st_obj_l = 0, st_refill = 0;
     uint32_t st_amb = 0, st_amb_l = 0;
     uint64_t tk_node = 0, tk_tri = 0, tk_obj = 0, tk_all = 0, tk0 = 0, tk1 = 0;
@@ -430,11 +430,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     v.w = (uint32_t)(tb >> 32);
                     *reinterpret_cast<uint4 *>(out_hits + out_index) = v;
                 }
-                if (FULL && out_points) {
-                    Ray ray{mk(COLD(C_OX), COLD(C_OY), COLD(C_OZ)), mk(COLD(C_DX), COLD(C_DY), COLD(C_DZ))};
-                    scene_point<PATCH>(s, ray, sh, out_points[out_index]);
-                }
-                if (FULL && out_counters) {
+                if (COUNT) {
                     out_counters[out_index].nodes_visited = ctr.nodes;
                     out_counters[out_index].tris_tested = ctr.tris;
                 }
@@ -638,7 +634,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     vf2 cz = {__uint_as_float(h1.x), __uint_as_float(h1.y)};
                     skip = h1.z;
                     leaf_ref = h1.w;
-                    if (FULL) ctr.nodes++;
+                    if (COUNT) ctr.nodes++;
                     vf2 qx = __builtin_elementwise_fma(cx, (vf2){r32x, r32x}, (vf2){np32x, np32x});
                     vf2 qy = __builtin_elementwise_fma(cy, (vf2){r32y, r32y}, (vf2){np32y, np32y});
                     vf2 qz = __builtin_elementwise_fma(cz, (vf2){r32z, r32z}, (vf2){np32z, np32z});
@@ -665,7 +661,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     V3 lo, hi;
                     uint4 tail;
                     load_node_g(node, lo, hi, tail);
-                    if (FULL) ctr.nodes++;
+                    if (COUNT) ctr.nodes++;
                     go = slow_any ? box_hit_div(lo, hi, in, h.t) : box_hit_fast(lo, hi, in, rcp, h.t);
                     skip = tail.x;
                     leaf_ref = tail.w == 0 ? 0xFFFFFFFFu : (tail.w == 1 ? tail.z : 0x80000000u);
@@ -712,7 +708,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 }
                 holder_add(h, some, t, leaf);
                 if (PRE) b32 = (float)h.t;       // an empty holder keeps t = +inf
-                if (FULL) ctr.tris++;
+                if (COUNT) ctr.tris++;
                 bool more = false;
                 if (leaf_cur & 0x80000000u) {    // rare: the owning node (cur - 1) lists several leaves
                     typedef const vu4 __attribute__((address_space(1))) *U4;
@@ -826,7 +822,7 @@ hipError_t launch_selftest_div(hipStream_t stream, uint64_t seed, uint32_t block
 template <class Source>
 static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Source &src, uint64_t n_items,
                                 uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits,
-                                rtg_point *out_points, rtg_ray_counters *out_counters) {
+                                rtg_ray_counters *out_counters) {
     if (n_items == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(work_counters, 0, (8 * kCounterStride + 16) * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
@@ -834,36 +830,41 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     uint64_t want = (chunks + 3) / 4;
     uint32_t grid = (uint32_t)(want < tune.max_blocks ? want : tune.max_blocks);
     if (grid == 0) grid = 1;
-    // the outer ray is needed after the first object when there are more objects, when point records are wanted,
-    // or when the first object is not a staged mesh; only then does the dynamic LDS hold it (9 cold fields per lane
-    // instead of 3)
-    const bool full = out_counters != nullptr || out_points != nullptr;
-    const bool keep = full || s.n_objects > 1 || !s.first_is_mesh;
+    // the outer ray is needed after the first object when there are more objects or when the first object is not a
+    // staged mesh; only then does the dynamic LDS hold it (9 cold fields per lane instead of 3)
+    const bool count = out_counters != nullptr;
+    const bool keep = s.n_objects > 1 || !s.first_is_mesh;
     const bool pre = tune.pretest && s.any_f32_ok;
     PhasedParams prm{s.has_patches ? tune.patch_tri_min : tune.tri_min, tune.obj_min};
     const size_t cold_bytes = (size_t)(keep ? 9 : 3) * kBlock * sizeof(double);
     dim3 g(grid), b(kBlock);
-#define RTG_L(F, X, P, K, S)                                                                                      \
-    hipLaunchKernelGGL((k_trace_phased<Source, F, X, P, K, S>), g, b, cold_bytes, stream, s, src, n_items,       \
-                       work_counters, prm, out_hits, out_points, out_counters)
-#define RTG_L_PRE(F, X, K, S) \
+#define RTG_L(C, X, P, K, S)                                                                                      \
+    hipLaunchKernelGGL((k_trace_phased<Source, C, X, P, K, S>), g, b, cold_bytes, stream, s, src, n_items,       \
+                       work_counters, prm, out_hits, out_counters)
+#define RTG_L_PRE(C, X, K, S) \
     do {                      \
         if (pre)              \
-            RTG_L(F, X, true, K, S);  \
+            RTG_L(C, X, true, K, S);  \
         else                  \
-            RTG_L(F, X, false, K, S); \
+            RTG_L(C, X, false, K, S); \
     } while (0)
-    if (tune.stats && !full && !keep && !s.has_patches) {
+#define RTG_L_KEEP(C, X, S) \
+    do {                    \
+        if (keep)           \
+            RTG_L_PRE(C, X, true, S);  \
+        else                \
+            RTG_L_PRE(C, X, false, S); \
+    } while (0)
+    if (tune.stats && !count && !keep && !s.has_patches) {
         RTG_L_PRE(false, false, false, true);
     } else if (s.has_patches) {
-        if (full) RTG_L_PRE(true, true, true, false);
-        else if (keep) RTG_L_PRE(false, true, true, false);
-        else RTG_L_PRE(false, true, false, false);
+        if (count) RTG_L_KEEP(true, true, false);
+        else RTG_L_KEEP(false, true, false);
     } else {
-        if (full) RTG_L_PRE(true, false, true, false);
-        else if (keep) RTG_L_PRE(false, false, true, false);
-        else RTG_L_PRE(false, false, false, false);
+        if (count) RTG_L_KEEP(true, false, false);
+        else RTG_L_KEEP(false, false, false);
     }
+#undef RTG_L_KEEP
 #undef RTG_L_PRE
 #undef RTG_L
     return hipGetLastError();
@@ -871,7 +872,7 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
 
 hipError_t launch_render_primary_phased(hipStream_t stream, const DevScene &s, const rtg_view &view, uint32_t width,
                                         uint32_t height, rtg_rect tile, uint32_t *work_counters,
-                                        const PhasedTuning &tune, rtg_hit *out_hits, rtg_point *out_points,
+                                        const PhasedTuning &tune, rtg_hit *out_hits,
                                         rtg_ray_counters *out_counters) {
     PrimarySource src;
     src.view = view;
@@ -880,16 +881,16 @@ hipError_t launch_render_primary_phased(hipStream_t stream, const DevScene &s, c
     src.tile = tile;
     src.tiles_x = (tile.w + 7) / 8;
     uint64_t tiles = (uint64_t)src.tiles_x * ((tile.h + 7) / 8);
-    return launch_phased(stream, s, src, tiles * 64, work_counters, tune, out_hits, out_points, out_counters);
+    return launch_phased(stream, s, src, tiles * 64, work_counters, tune, out_hits, out_counters);
 }
 
 hipError_t launch_trace_phased(hipStream_t stream, const DevScene &s, const double *rays6, uint64_t n,
                                uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits,
-                               rtg_point *out_points, rtg_ray_counters *out_counters) {
+                               rtg_ray_counters *out_counters) {
     BatchSource src;
     src.rays6 = rays6;
     src.n = n;
-    return launch_phased(stream, s, src, n, work_counters, tune, out_hits, out_points, out_counters);
+    return launch_phased(stream, s, src, n, work_counters, tune, out_hits, out_counters);
 }
 
 hipError_t launch_shadow_phased(hipStream_t stream, const DevScene &s, const rtg_point *points, uint64_t n_points,
@@ -900,7 +901,7 @@ hipError_t launch_shadow_phased(hipStream_t stream, const DevScene &s, const rtg
     src.lights = lights;
     src.n_points = n_points;
     src.n_lights = n_lights;
-    return launch_phased(stream, s, src, n_points * n_lights, work_counters, tune, out_occluders, nullptr, nullptr);
+    return launch_phased(stream, s, src, n_points * n_lights, work_counters, tune, out_occluders, nullptr);
 }
 
 } // namespace rtg
