@@ -325,6 +325,62 @@ def test_frame_of_opaque_scene_in_passes(gpu_ctx, traversal):
     gpu_ctx.set_option("traversal", 2)
 
 
+@pytest.mark.parametrize("traversal", TRAVERSALS)
+def test_many_instances_with_general_affine_transforms(gpu_ctx, traversal):
+    """Twenty objects: two meshes instanced under rotated, sheared and mirrored transforms (Transform::from on an
+    arbitrary forward matrix, src/geo/transform.rs:51-80), spheres, planes and a glass ball in between, so the object
+    list is walked through meshes and primitives in every order and the scene-level minimum sees many candidates."""
+    gpu_ctx.set_option("traversal", traversal)
+    rng = np.random.default_rng(77)
+    tris_a, _ = scenes.terrain(30, 30, seed=3, local_scale=1.0)
+    tris_b, _ = scenes.terrain(20, 40, seed=4, local_scale=1.0)
+    bvh_a = rtg.HostBvh(tris_a, vertex_normals=scenes.vertex_normals_for(tris_a))
+    bvh_b = rtg.HostBvh(tris_b)
+
+    def affine():
+        m = np.eye(4)
+        a = rng.normal(size=(3, 3))
+        q, _ = np.linalg.qr(a)                                    # rotation or reflection
+        shear = np.eye(3) + np.triu(rng.uniform(-0.3, 0.3, size=(3, 3)), 1)
+        m[:3, :3] = q @ shear @ np.diag(rng.uniform(0.2, 0.6, size=3))
+        m[:3, 3] = rng.uniform(-0.6, 0.6, size=3) + [0, 0, -1.0]
+        return rtg.transform_from_forward(m)
+
+    objs, meshes = [], {}
+    for i in range(20):
+        kind = i % 5
+        if kind in (0, 3):
+            objs.append(rtg.mesh_object(None, rtg.material(tuple(rng.uniform(0.2, 1, size=3))), affine()))
+            meshes[i] = bvh_a if kind == 0 else bvh_b
+        elif kind == 1:
+            objs.append(rtg.sphere_object(tuple(rng.uniform(-0.5, 0.5, size=3) + [0, 0, -1.2]), float(rng.uniform(0.05, 0.2)),
+                                          rtg.material((0.5, 0.5, 0.9), dielectric=(1.0, 1.5) if i == 6 else None), affine() if i > 10 else None))
+        elif kind == 2:
+            objs.append(rtg.plane_object((0, -0.8 - 0.01 * i, 0), (0, 0, -1), (-1, 0, 0), rtg.material((1, 1, 1)), rtg.material((0.1, 0.1, 0.1))))
+        else:
+            objs.append(rtg.sphere_object((0.0, 0.0, -3.0 - i), 0.5, rtg.material((0.3, 0.8, 0.3))))
+    pair = scenes.Pair(gpu_ctx, objs, meshes)
+    _, lights, view = scenes.default_objects(9)
+    w, h = 192, 144
+    g_hits, g_pts, g_ctr = pair.gpu.render_primary(view, w, h, points=True, counters=True)
+    c_hits, c_pts, c_ctr = pair.cpu.render_primary(view, w, h, points=True, counters=True)
+    _assert_hits_equal(g_hits, c_hits)
+    _assert_points_equal(g_pts, c_pts)
+    assert np.array_equal(g_ctr, c_ctr)
+    assert len(np.unique(g_hits["object"])) >= 8
+    g_rgb, g_c8, g_hits = pair.gpu.render_frame(view, lights, w, h, max_depth=4)
+    c_rgb, c_c8, c_hits = pair.cpu.render_frame(view, lights, w, h, max_depth=4)
+    _assert_hits_equal(g_hits, c_hits)
+    assert not scenes.float_bits_differ(g_rgb, c_rgb).any()
+    assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1
+    rays = np.concatenate([rng.uniform(-1, 1, size=(20000, 3)) + [0, 0, -1], rng.normal(size=(20000, 3))], axis=1)
+    g_hits, g_pts, _ = pair.gpu.trace(rays, points=True)
+    c_hits, c_pts, _ = pair.cpu.trace(rays, points=True)
+    _assert_hits_equal(g_hits, c_hits)
+    _assert_points_equal(g_pts, c_pts)
+    gpu_ctx.set_option("traversal", 2)
+
+
 def test_device_f64_div_and_sqrt_are_correctly_rounded(gpu_ctx):
     """The parity argument rests on IEEE-exact device / and sqrt: sweep them through the ray normalisation."""
     import math
