@@ -19,9 +19,18 @@
 //     (blocks b and b+8 share an XCD and its L2, so each XCD first drains its
 //     own contiguous eighth of the frame and only then helps the others).
 //
-// The box test divides by the ray direction six times per node.  The
-// direction is constant per ray, so the quotient is rebuilt from r = 1/d
-// (one IEEE division per ray and axis) with two FMA refinement steps:
+// Rays are prepared a chunk at a time: the wave that takes a chunk generates
+// its 64 rays with every lane busy, carries them into the first mesh's space
+// and parks them in LDS; a lane that needs a ray copies one slot.
+//
+// The box test of a visit is decided in single precision on a 32-byte
+// companion node whenever a rigorous error bound allows it (PreRay below); the
+// few visits that are too close to call, and rays or meshes outside the
+// magnitude window of the bound, run the reference's f64 test.  Builds without
+// the pre-test replace the six divisions of the f64 test by an exact
+// reciprocal form: the direction is constant per ray, so the quotient is
+// rebuilt from r = 1/d (one IEEE division per ray and axis) with two FMA
+// refinement steps,
 //   q0 = x*r; e0 = fma(-q0,d,x); q1 = fma(e0,r,q0); e1 = fma(-q1,d,x); q = fma(e1,r,q1)
 // q1 is a faithful quotient, the residual e1 is then exact, and with r the
 // correctly rounded reciprocal the last step returns the correctly rounded
