@@ -56,6 +56,8 @@ struct rtg_scene {
     void *d_objects = nullptr;
     uint32_t max_depth = 0;
     bool any_dielectric = false;   // some material refracts: frames need the specular path tree
+    bool has_mesh = false;         // some object is a mesh or patch set: shading is worth doing as passes of the
+                                   // persistent kernel (sphere/plane-only scenes are cheaper in one fused launch)
 };
 
 namespace {
@@ -688,6 +690,7 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
         const rtg_object &o = desc->objects[i];
         if (o.kind == RTG_PATCHES) s->dev.has_patches = 1;
         if ((o.kind == RTG_MESH || o.kind == RTG_PATCHES) && o.mesh->dev.f32_ok) s->dev.any_f32_ok = 1;
+        if ((o.kind == RTG_MESH || o.kind == RTG_PATCHES) && o.mesh->dev.n_nodes != 0) s->has_mesh = true;
     }
     *out = s;
     return RTG_OK;
@@ -782,20 +785,116 @@ int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *o
 
 namespace {
 // compute_direct_irrad for device-resident points through the persistent kernel: one closest-hit launch over all
-// (light, point) shadow rays, then one resolve pass.
+// (light, point) shadow rays -- and, in the same launch, over `n_rays` further rays whose hits land behind the
+// occluder table (*ray_hits) -- then one resolve pass.
 int shade_wavefront(rtg_ctx *ctx, const DevScene &ds, const rtg_light *d_lights, uint32_t n_lights,
-                    const rtg_point *d_points, uint64_t n_points, double *d_rgb, uint8_t *d_rgba8) {
+                    const rtg_point *d_points, uint64_t n_points, double *d_rgb, uint8_t *d_rgba8,
+                    const double *d_rays = nullptr, uint64_t n_rays = 0, const rtg_hit **ray_hits = nullptr) {
     int rc;
     void *occ = nullptr;
-    if (n_lights != 0) {
+    const uint64_t n_shadow = (uint64_t)n_lights * n_points;
+    if (n_shadow + n_rays != 0) {
         void *wc = nullptr;
         if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
-        if ((rc = scratch_get(ctx, "occluders", (size_t)n_lights * n_points * sizeof(rtg_hit), &occ)) != RTG_OK) return rc;
-        HIP_TRY(ctx, launch_shadow_phased(ctx->stream, ds, d_points, n_points, d_lights, n_lights, (uint32_t *)wc,
-                                          ctx->tune, (rtg_hit *)occ));
+        if ((rc = scratch_get(ctx, "occluders", (size_t)(n_shadow + n_rays) * sizeof(rtg_hit), &occ)) != RTG_OK) return rc;
+        HIP_TRY(ctx, launch_shadow_phased(ctx->stream, ds, d_points, n_points, d_lights, n_lights, d_rays, n_rays,
+                                          (uint32_t *)wc, ctx->tune, (rtg_hit *)occ));
     }
+    if (ray_hits) *ray_hits = (const rtg_hit *)occ + n_shadow;
     HIP_TRY(ctx, launch_shade_resolve(ctx->stream, ds, d_lights, n_lights, d_points, n_points, (const rtg_hit *)occ,
                                       d_rgb, d_rgba8));
+    return RTG_OK;
+}
+
+// Shading of a frame whose primary point records `pts0` are built, with the specular path tree as levels of ray
+// batches when `spec`: per level, the rays of the next level are spawned from the current points, one launch traces
+// them together with the current level's shadow rays, the resolve pass shades the current level and its radiance is
+// parked per path-tree slot; at the end the refracting pixels are re-summed in the reference's depth-first order.
+// *done is false when the slot table would exceed the memory budget (the caller then lets the fused kernel redo the
+// refracting pixels).
+int frame_wavefront(rtg_ctx *ctx, const DevScene &ds, const rtg_view &view, uint32_t width, uint32_t height, rtg_rect tile,
+                    const rtg_light *d_lights, uint32_t n_lights, const rtg_point *pts0, uint64_t n, uint32_t max_depth,
+                    bool spec, double *frame_rgb, double *d_rgb, uint8_t *d_rgba8, bool *done) {
+    int rc;
+    *done = true;
+    uint32_t *cnt = nullptr;                  // [0] rays spawned, [1] slot groups opened, [2] refracting hits
+    uint32_t host_cnt[4] = {0, 0, 0, 0};
+    if (spec) {
+        void *v = nullptr;
+        if ((rc = scratch_get(ctx, "spec_counters", 4 * sizeof(uint32_t), &v)) != RTG_OK) return rc;
+        cnt = (uint32_t *)v;
+        HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 4 * sizeof(uint32_t), ctx->stream));
+    }
+    auto read_counters = [&]() -> int {
+        HIP_TRY(ctx, hipMemcpyAsync(host_cnt, cnt, sizeof(host_cnt), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return RTG_OK;
+    };
+    const uint32_t slots_per_group = (1u << max_depth) - 1u;
+    const char *ray_names[2] = {"spec_rays_0", "spec_rays_1"}, *meta_names[2] = {"spec_meta_0", "spec_meta_1"};
+    void *rays[2] = {nullptr, nullptr}, *meta[2] = {nullptr, nullptr}, *groups = nullptr, *slots = nullptr;
+    uint32_t n_groups = 0;
+    int cur = 0;                              // rays[cur] / meta[cur] describe the current level when depth >= 1
+    const rtg_point *pts = pts0;
+    uint64_t m = n;
+    for (uint32_t depth = 0;; depth++) {
+        // rays of the next level, spawned from this level's points
+        uint64_t m_next = 0;
+        const int nxt = depth == 0 ? 0 : cur ^ 1;
+        if (spec && depth + 1 < max_depth && m != 0) {
+            HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(cnt + 2, 0, sizeof(uint32_t), ctx->stream));
+            HIP_TRY(ctx, launch_spec_count(ctx->stream, ds, pts, m, cnt + 2));
+            if ((rc = read_counters()) != RTG_OK) return rc;
+            const uint32_t k = host_cnt[2];
+            if (k != 0 && depth == 0) {
+                n_groups = k;
+                const size_t slot_bytes = (size_t)n_groups * slots_per_group * 4 * sizeof(double);
+                if (slot_bytes > ((size_t)2 << 30)) {
+                    *done = false;
+                    spec = false;
+                } else {
+                    if ((rc = scratch_get(ctx, "spec_groups", (size_t)n_groups * sizeof(uint32_t), &groups)) != RTG_OK) return rc;
+                    if ((rc = scratch_get(ctx, "spec_slots", slot_bytes, &slots)) != RTG_OK) return rc;
+                    HIP_TRY(ctx, hipMemsetAsync(slots, 0, slot_bytes, ctx->stream));
+                }
+            }
+            if (k != 0 && spec) {
+                if ((rc = scratch_get(ctx, ray_names[nxt], (size_t)k * 2 * 6 * sizeof(double), &rays[nxt])) != RTG_OK) return rc;
+                if ((rc = scratch_get(ctx, meta_names[nxt], (size_t)k * 2 * sizeof(SpecMeta), &meta[nxt])) != RTG_OK) return rc;
+                HIP_TRY(ctx, launch_spec_spawn(ctx->stream, ds, view, width, height, tile,
+                                               depth == 0 ? nullptr : (const double *)rays[cur],
+                                               depth == 0 ? nullptr : (const SpecMeta *)meta[cur], pts, m, depth, max_depth,
+                                               (double *)rays[nxt], (SpecMeta *)meta[nxt], (uint32_t *)groups, cnt));
+                if ((rc = read_counters()) != RTG_OK) return rc;
+                m_next = host_cnt[0];
+            }
+        }
+        // this level's shadow rays and the next level's rays in one launch, then this level's radiance
+        double *rgb = frame_rgb;
+        if (depth != 0) {
+            void *v = nullptr;
+            if ((rc = scratch_get(ctx, "spec_rgb", m * 3 * sizeof(double), &v)) != RTG_OK) return rc;
+            rgb = (double *)v;
+        }
+        const rtg_hit *next_hits = nullptr;
+        if ((rc = shade_wavefront(ctx, ds, d_lights, n_lights, pts, m, rgb, depth == 0 ? d_rgba8 : nullptr,
+                                  m_next ? (const double *)rays[nxt] : nullptr, m_next, &next_hits)) != RTG_OK)
+            return rc;
+        if (depth != 0)
+            HIP_TRY(ctx, launch_spec_store(ctx->stream, (const SpecMeta *)meta[cur], pts, rgb, m, slots_per_group,
+                                           (double *)slots));
+        if (m_next == 0) break;
+        void *v = nullptr;
+        if ((rc = scratch_get(ctx, "spec_points", m_next * sizeof(rtg_point), &v)) != RTG_OK) return rc;
+        HIP_TRY(ctx, launch_points_batch(ctx->stream, ds, (const double *)rays[nxt], m_next, next_hits, (rtg_point *)v));
+        pts = (const rtg_point *)v;
+        m = m_next;
+        cur = nxt;
+    }
+    if (n_groups != 0 && *done)
+        HIP_TRY(ctx, launch_spec_sum(ctx->stream, (const uint32_t *)groups, n_groups, slots_per_group, (const double *)slots,
+                                     frame_rgb, d_rgb, d_rgba8));
     return RTG_OK;
 }
 } // namespace
@@ -820,7 +919,7 @@ int rtg_shade_direct(rtg_scene *scene, const rtg_light *lights, uint32_t n_light
     DevScene ds;
     uint64_t threads = (n_points + kBlock - 1) / kBlock * kBlock;
     if ((rc = scene_for_launch(scene, threads, ds)) != RTG_OK) return rc;
-    if (ctx->traversal == 2) {
+    if (ctx->traversal == 2 && scene->has_mesh) {
         if ((rc = shade_wavefront(ctx, ds, (const rtg_light *)d_lights, n_lights, (const rtg_point *)d_points, n_points,
                                   (double *)orgb.dev, (uint8_t *)o8.dev)) != RTG_OK)
             return rc;
@@ -859,9 +958,11 @@ int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *li
     if ((rc = out_prepare(ctx, "out_hits", out_hits, n * sizeof(rtg_hit), oh)) != RTG_OK) return rc;
     DevScene ds;
     if ((rc = scene_for_launch(scene, tiles * kBlock, ds)) != RTG_OK) return rc;
-    if (ctx->traversal == 2 && max_depth >= 1 && !scene->any_dielectric && n_lights <= (1ull << 37) / n) {
-        // no refracting material: every pixel is one primary hit plus its shadow rays, so the frame is three passes
-        // of the persistent kernel's building blocks (primary hits with point records, shadow rays, resolve)
+    if (ctx->traversal == 2 && scene->has_mesh && max_depth >= 1 && n_lights <= (1ull << 37) / n) {
+        // Every pixel is one primary hit plus its shadow rays unless that hit refracts, so the frame is passes of the
+        // persistent kernel's building blocks (primary hit ids, point records, shadow rays, resolve); the pixels
+        // whose primary hit has a dielectric material -- the only ones with a path tree -- are then redone by the
+        // fused kernel.
         void *wc = nullptr, *pts = nullptr;
         if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
         if ((rc = scratch_get(ctx, "frame_points", n * sizeof(rtg_point), &pts)) != RTG_OK) return rc;
@@ -869,13 +970,25 @@ int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *li
         if (!hits && (rc = scratch_get(ctx, "points_hits", n * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
         HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, (uint32_t *)wc, ctx->tune,
                                                   (rtg_hit *)hits, nullptr));
-        if (orgb.dev || o8.dev)
+        if (orgb.dev || o8.dev) {
+            const bool spec = scene->any_dielectric && max_depth > 1;
+            void *frame_rgb = orgb.dev;          // the path-tree re-sum needs the linear radiance of level 0
+            if (spec && !frame_rgb && (rc = scratch_get(ctx, "frame_rgb", n * 3 * sizeof(double), &frame_rgb)) != RTG_OK)
+                return rc;
             HIP_TRY(ctx, launch_points_primary(ctx->stream, ds, *view, width, height, tile, (const rtg_hit *)hits,
                                                (rtg_point *)pts));
-        if (orgb.dev || o8.dev)
-            if ((rc = shade_wavefront(ctx, ds, (const rtg_light *)d_lights, n_lights, (const rtg_point *)pts, n,
-                                      (double *)orgb.dev, (uint8_t *)o8.dev)) != RTG_OK)
+            bool done = true;
+            if ((rc = frame_wavefront(ctx, ds, *view, width, height, tile, (const rtg_light *)d_lights, n_lights,
+                                      (const rtg_point *)pts, n, max_depth, spec, (double *)frame_rgb, (double *)orgb.dev,
+                                      (uint8_t *)o8.dev, &done)) != RTG_OK)
                 return rc;
+            if (spec) {
+                if (!done)      // slot table over budget: the fused kernel redoes the refracting pixels
+                    HIP_TRY(ctx, launch_render_frame(ctx->stream, ds, *view, (const rtg_light *)d_lights, n_lights, width,
+                                                     height, tile, max_depth, (double *)orgb.dev, (uint8_t *)o8.dev,
+                                                     nullptr, (const rtg_point *)pts));
+            }
+        }
     } else {
         HIP_TRY(ctx, launch_render_frame(ctx->stream, ds, *view, (const rtg_light *)d_lights, n_lights, width, height,
                                          tile, max_depth, (double *)orgb.dev, (uint8_t *)o8.dev, (rtg_hit *)oh.dev));

@@ -812,6 +812,50 @@ __device__ __forceinline__ V3 direct_irrad(const DevScene &s, const rtg_light *l
     return lighting;
 }
 
+// Dielectric::new (render/dielectric.rs:13-52).
+struct Dielectric {
+    double reflectance;
+    V3 reflect, refract;
+    bool has_refract;
+};
+__device__ __forceinline__ Dielectric dielectric_new(V3 inc, V3 signed_norm, double n1, double n2) {
+    inc = normalize(inc);
+    double d = dot(inc, signed_norm);
+    V3 norm;
+    double cos_i, n_i, n_t;
+    if (d < 0.0) {
+        norm = signed_norm;
+        cos_i = -d;
+        n_i = n1;
+        n_t = n2;
+    } else {
+        norm = neg(signed_norm);
+        cos_i = d;
+        n_i = n2;
+        n_t = n1;
+    }
+    double eta = n_i / n_t;
+    double s2i = 1.0 - cos_i * cos_i;
+    // f64::maximum(x, 0.0): NaN propagates
+    s2i = is_nan(s2i) ? s2i : (s2i > 0.0 ? s2i : 0.0);
+    double s2t = eta * eta * s2i;
+    Dielectric r;
+    r.refract = mk(0.0, 0.0, 0.0);
+    if (s2t >= 1.0) {
+        r.has_refract = false;
+        r.reflectance = 1.0;
+    } else {
+        double cos_t = __builtin_sqrt(1.0 - s2t);
+        r.has_refract = true;
+        r.refract = inc * eta + norm * (eta * cos_i - cos_t);
+        double r_par = ((n_t * cos_i) - (n_i * cos_t)) / ((n_t * cos_i) + (n_i * cos_t));
+        double r_perp = ((n_i * cos_i) - (n_t * cos_t)) / ((n_i * cos_i) + (n_t * cos_t));
+        r.reflectance = (r_par * r_par + r_perp * r_perp) / 2.0;
+    }
+    r.reflect = inc - (norm * 2.0) * dot(inc, norm);
+    return r;
+}
+
 // smpte2048_encode (geo/color.rs:5-17) of c/80 (render/image.rs:39), quantised
 // to 8 bits: round(255 * clamp01(e)).
 __device__ __forceinline__ uint8_t pq8(double c) {

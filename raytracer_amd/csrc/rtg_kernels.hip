@@ -198,50 +198,6 @@ __global__ __launch_bounds__(kBlock) void k_shade_resolve(DevScene s, const rtg_
     }
 }
 
-// Dielectric::new (render/dielectric.rs:13-52).
-struct Dielectric {
-    double reflectance;
-    V3 reflect, refract;
-    bool has_refract;
-};
-__device__ __forceinline__ Dielectric dielectric_new(V3 inc, V3 signed_norm, double n1, double n2) {
-    inc = normalize(inc);
-    double d = dot(inc, signed_norm);
-    V3 norm;
-    double cos_i, n_i, n_t;
-    if (d < 0.0) {
-        norm = signed_norm;
-        cos_i = -d;
-        n_i = n1;
-        n_t = n2;
-    } else {
-        norm = neg(signed_norm);
-        cos_i = d;
-        n_i = n2;
-        n_t = n1;
-    }
-    double eta = n_i / n_t;
-    double s2i = 1.0 - cos_i * cos_i;
-    // f64::maximum(x, 0.0): NaN propagates
-    s2i = is_nan(s2i) ? s2i : (s2i > 0.0 ? s2i : 0.0);
-    double s2t = eta * eta * s2i;
-    Dielectric r;
-    r.refract = mk(0.0, 0.0, 0.0);
-    if (s2t >= 1.0) {
-        r.has_refract = false;
-        r.reflectance = 1.0;
-    } else {
-        double cos_t = __builtin_sqrt(1.0 - s2t);
-        r.has_refract = true;
-        r.refract = inc * eta + norm * (eta * cos_i - cos_t);
-        double r_par = ((n_t * cos_i) - (n_i * cos_t)) / ((n_t * cos_i) + (n_i * cos_t));
-        double r_perp = ((n_i * cos_i) - (n_t * cos_t)) / ((n_i * cos_i) + (n_t * cos_t));
-        r.reflectance = (r_par * r_par + r_perp * r_perp) / 2.0;
-    }
-    r.reflect = inc - (norm * 2.0) * dot(inc, norm);
-    return r;
-}
-
 // Fused frame: raytrace_pixel (render/renderer.rs:266-283) with the photon term
 // empty.  The specular recursion (renderer.rs:296-378, depth cap at :312) is
 // unrolled into an explicit stack of pending rays: a dielectric hit schedules
@@ -255,12 +211,16 @@ struct Pending {
     uint32_t depth;
 };
 
+// With `only_refracting` set (the point records of the primary hits), the kernel redoes just the pixels whose
+// primary hit has a dielectric material -- the ones with more than one path -- and leaves the others as the
+// pass-structured renderer wrote them.
 template <bool PATCH>
 __global__ __launch_bounds__(kBlock) void k_render_frame(DevScene s, rtg_view view,
                                                           const rtg_light *__restrict__ lights, uint32_t n_lights,
                                                           uint32_t width, uint32_t height, rtg_rect tile,
                                                           uint32_t tiles_x, uint32_t n_tiles, uint32_t max_depth,
-                                                          double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits) {
+                                                          double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits,
+                                                          const rtg_point *__restrict__ only_refracting) {
     __shared__ uint32_t lds[kLdsLevels * kBlock];
     uint32_t t = xcd_remap(blockIdx.x, n_tiles);
     uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
@@ -269,6 +229,10 @@ __global__ __launch_bounds__(kBlock) void k_render_frame(DevScene s, rtg_view vi
     uint32_t py = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
     if (px >= tile.w || py >= tile.h) return;
     uint64_t idx = (uint64_t)py * tile.w + px;
+    if (only_refracting) {
+        const rtg_point &p0 = only_refracting[idx];
+        if (p0.manifold_len == 0 || !material_of_slot(s, p0.material_slot).has_dielectric) return;
+    }
     TraceCtx tc = make_trace_ctx(s, lds, (uint64_t)blockIdx.x * kBlock + threadIdx.x);
     Counter ctr;
 
@@ -439,17 +403,18 @@ hipError_t launch_shade_resolve(hipStream_t stream, const DevScene &s, const rtg
 
 hipError_t launch_render_frame(hipStream_t stream, const DevScene &s, const rtg_view &view, const rtg_light *lights,
                                uint32_t n_lights, uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth,
-                               double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits) {
+                               double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits,
+                               const rtg_point *only_refracting) {
     uint32_t tiles_x = div_up(tile.w, 16), tiles_y = div_up(tile.h, 16);
     uint32_t n_tiles = tiles_x * tiles_y;
     if (n_tiles == 0) return hipSuccess;
     dim3 grid(n_tiles), block(kBlock);
     if (s.has_patches)
         hipLaunchKernelGGL(k_render_frame<true>, grid, block, 0, stream, s, view, lights, n_lights, width, height, tile,
-                           tiles_x, n_tiles, max_depth, out_rgb, out_rgba8, out_hits);
+                           tiles_x, n_tiles, max_depth, out_rgb, out_rgba8, out_hits, only_refracting);
     else
         hipLaunchKernelGGL(k_render_frame<false>, grid, block, 0, stream, s, view, lights, n_lights, width, height, tile,
-                           tiles_x, n_tiles, max_depth, out_rgb, out_rgba8, out_hits);
+                           tiles_x, n_tiles, max_depth, out_rgb, out_rgba8, out_hits, only_refracting);
     return hipGetLastError();
 }
 

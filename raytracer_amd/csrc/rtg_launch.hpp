@@ -15,7 +15,8 @@ hipError_t launch_shade_direct(hipStream_t stream, const DevScene &s, const rtg_
                                const rtg_point *points, uint64_t n, double *rgb_out, uint8_t *rgba8_out);
 hipError_t launch_render_frame(hipStream_t stream, const DevScene &s, const rtg_view &view, const rtg_light *lights,
                                uint32_t n_lights, uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth,
-                               double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits);
+                               double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits,
+                               const rtg_point *only_refracting = nullptr);
 
 // Persistent phase-scheduled kernels (rtg_phased.hip).
 struct PhasedTuning {
@@ -39,14 +40,32 @@ hipError_t launch_points_primary(hipStream_t stream, const DevScene &s, const rt
 hipError_t launch_points_batch(hipStream_t stream, const DevScene &s, const double *rays6, uint64_t n,
                                const rtg_hit *hits, rtg_point *out_points);
 
-// Closest hit along the shadow ray of every (light, point) pair that has one; out_occluders[l * n_points + p].
+// Closest hit along the shadow ray of every (light, point) pair that has one, out_hits[l * n_points + p], and in
+// the same launch the closest hits of `n_rays` batch rays, out_hits[n_lights * n_points + i].
 hipError_t launch_shadow_phased(hipStream_t stream, const DevScene &s, const rtg_point *points, uint64_t n_points,
-                                const rtg_light *lights, uint32_t n_lights, uint32_t *work_counters,
-                                const PhasedTuning &tune, rtg_hit *out_occluders);
+                                const rtg_light *lights, uint32_t n_lights, const double *rays6, uint64_t n_rays,
+                                uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits);
 // compute_direct_irrad x diffuse from occluders found by launch_shadow_phased.
 hipError_t launch_shade_resolve(hipStream_t stream, const DevScene &s, const rtg_light *lights, uint32_t n_lights,
                                 const rtg_point *points, uint64_t n, const rtg_hit *occluders, double *rgb_out,
                                 uint8_t *rgba8_out);
+
+// Specular path tree as levels of ray batches (rtg_specular.hip).
+struct SpecMeta {
+    uint32_t group;        // slot group of the refracting pixel the ray descends from
+    uint32_t slot;         // pre-order index of the ray's node in that pixel's path tree
+    double attenuation;
+};
+hipError_t launch_spec_count(hipStream_t stream, const DevScene &s, const rtg_point *points, uint64_t n,
+                             uint32_t *counter);
+hipError_t launch_spec_spawn(hipStream_t stream, const DevScene &s, const rtg_view &view, uint32_t width,
+                             uint32_t height, rtg_rect tile, const double *rays6, const SpecMeta *meta,
+                             const rtg_point *points, uint64_t n, uint32_t depth, uint32_t max_depth,
+                             double *next_rays6, SpecMeta *next_meta, uint32_t *groups, uint32_t *counters);
+hipError_t launch_spec_store(hipStream_t stream, const SpecMeta *meta, const rtg_point *points, const double *rgb,
+                             uint64_t n, uint32_t slots_per_group, double *slots);
+hipError_t launch_spec_sum(hipStream_t stream, const uint32_t *groups, uint32_t n_groups, uint32_t slots_per_group,
+                           const double *slots, double *frame_rgb, double *out_rgb, uint8_t *out_rgba8);
 
 hipError_t launch_selftest_div(hipStream_t stream, uint64_t seed, uint32_t blocks, uint32_t per_thread, uint32_t family,
                                uint64_t *out3);

@@ -117,6 +117,21 @@ struct ShadowSource {
     }
 };
 
+// Shadow rays of one level of the path tree and the traced rays of the next level in one launch: items below
+// n_shadow are ShadowSource items, the rest are batch rays; the output slot is the item index, so the hit buffer is
+// the occluder table followed by the batch hits.
+struct ShadowAndBatchSource {
+    ShadowSource shadow;
+    BatchSource batch;
+    uint64_t n_shadow;
+    __device__ __forceinline__ uint64_t slot_of(uint64_t item) const { return item; }
+    __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
+        bool ok = item < n_shadow ? shadow.make(item, ray, out_index) : batch.make(item - n_shadow, ray, out_index);
+        out_index = item;
+        return ok;
+    }
+};
+
 // ---- exact division by a per-ray constant ------------------------------------------
 __device__ __forceinline__ double div_by_const(double x, double d, double r) {
     double q0 = x * r;
@@ -903,14 +918,20 @@ hipError_t launch_trace_phased(hipStream_t stream, const DevScene &s, const doub
 }
 
 hipError_t launch_shadow_phased(hipStream_t stream, const DevScene &s, const rtg_point *points, uint64_t n_points,
-                                const rtg_light *lights, uint32_t n_lights, uint32_t *work_counters,
-                                const PhasedTuning &tune, rtg_hit *out_occluders) {
-    ShadowSource src;
-    src.points = points;
-    src.lights = lights;
-    src.n_points = n_points;
-    src.n_lights = n_lights;
-    return launch_phased(stream, s, src, n_points * n_lights, work_counters, tune, out_occluders, nullptr);
+                                const rtg_light *lights, uint32_t n_lights, const double *rays6, uint64_t n_rays,
+                                uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits) {
+    ShadowSource shadow;
+    shadow.points = points;
+    shadow.lights = lights;
+    shadow.n_points = n_points;
+    shadow.n_lights = n_lights;
+    if (n_rays == 0) return launch_phased(stream, s, shadow, n_points * n_lights, work_counters, tune, out_hits, nullptr);
+    ShadowAndBatchSource src;
+    src.shadow = shadow;
+    src.batch.rays6 = rays6;
+    src.batch.n = n_rays;
+    src.n_shadow = n_points * n_lights;
+    return launch_phased(stream, s, src, src.n_shadow + n_rays, work_counters, tune, out_hits, nullptr);
 }
 
 } // namespace rtg

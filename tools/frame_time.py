@@ -9,13 +9,18 @@ from raytracer_amd import rtg
 import bench, scenes
 
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
+TRAVERSAL = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 tris = rtg.heightfield(1000, 500, bench.SEED, bench.LOCAL_SCALE)
 bvh = rtg.HostBvh(tris)
 ctx = rtg.Context(0)
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); ctx.set_stream(stream.cuda_stream)
+ctx.set_option("traversal", TRAVERSAL)
 mesh = ctx.mesh(bvh)
 _, lights, view = scenes.default_objects(0)
-for label, objs in (("mesh only", [rtg.mesh_object(mesh, rtg.material((0.8, 0.7, 0.6)), rtg.transform(1.0 / bench.LOCAL_SCALE))]),):
+mesh_obj = rtg.mesh_object(mesh, rtg.material((0.8, 0.7, 0.6)), rtg.transform(1.0 / bench.LOCAL_SCALE))
+default_objs, _, _ = scenes.default_objects(0)      # glass sphere + checker plane
+for label, objs in (("mesh only", [mesh_obj]), ("glass sphere + plane + mesh", list(default_objs) + [mesh_obj]),
+                    ("glass sphere + plane", list(default_objs))):
     scene = ctx.scene(objs)
     rgba = torch.empty(W * H * 4, dtype=torch.uint8, device="cuda")
     def run():
@@ -26,4 +31,4 @@ for label, objs in (("mesh only", [rtg.mesh_object(mesh, rtg.material((0.8, 0.7,
     for _ in range(5): run()
     b.record(stream); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 5
-    print(f"{label}: {W}x{H} frame {ms:.2f} ms ({W*H/ms/1e3:.1f} Mpixels/s)")
+    print(f"traversal {TRAVERSAL}, {label}: {W}x{H} frame {ms:.2f} ms ({W*H/ms/1e3:.1f} Mpixels/s)")
