@@ -381,6 +381,63 @@ def test_many_instances_with_general_affine_transforms(gpu_ctx, traversal):
     gpu_ctx.set_option("traversal", 2)
 
 
+def _glass_scene(rng_seed=5):
+    tris, xform = scenes.terrain(40, 40, seed=rng_seed)
+    bvh = rtg.HostBvh(tris, vertex_normals=scenes.vertex_normals_for(tris))
+    tris2, _ = scenes.terrain(12, 12, seed=rng_seed + 1, local_scale=1.0)
+    bvh2 = rtg.HostBvh(tris2)
+    _, lights, view = scenes.default_objects(11)
+    objs = [
+        rtg.sphere_object((0.0, -0.2, 0.0), 0.2, rtg.material((0.0, 0.0, 0.0), dielectric=(1.0, 1.5))),
+        rtg.plane_object((0, -0.5, 0), (0, 0, -1), (-1, 0, 0), rtg.material((1, 1, 1)), rtg.material((0.1, 0.1, 0.1))),
+        rtg.mesh_object(None, rtg.material((0.8, 0.7, 0.6)), xform),
+        rtg.sphere_object((0.35, 0.1, -0.2), 0.15, rtg.material((0.2, 0.1, 0.1), dielectric=(1.0, 1.33))),
+        # a small refracting mesh in front of everything
+        rtg.mesh_object(None, rtg.material((0.1, 0.2, 0.1), dielectric=(1.0, 1.2)), rtg.transform(0.12, (-3.0, 1.0, 3.0))),
+    ]
+    return objs, {2: bvh, 4: bvh2}, lights, view
+
+
+@pytest.mark.parametrize("max_depth", [2, 3, 5, 8])
+def test_specular_tree_as_ray_batch_levels(gpu_ctx, max_depth):
+    """Frames with refracting spheres and a refracting mesh: the default traversal renders the path tree level by
+    level (spawn, trace with the previous level's shadow rays, shade, park per slot, re-sum depth first) and must
+    give the recursion's radiance bit for bit -- on a full frame, a ragged tile, and with only 8-bit output."""
+    objs, meshes, lights, view = _glass_scene()
+    pair = scenes.Pair(gpu_ctx, objs, meshes)
+    w, h = 176, 132
+    for tile in (None, (21, 9, 130, 101)):
+        g_rgb, g_c8, g_hits = pair.gpu.render_frame(view, lights, w, h, tile=tile, max_depth=max_depth)
+        c_rgb, c_c8, c_hits = pair.cpu.render_frame(view, lights, w, h, tile=tile, max_depth=max_depth)
+        _assert_hits_equal(g_hits, c_hits)
+        assert not scenes.float_bits_differ(g_rgb, c_rgb).any()
+        assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1
+    glass = np.isin(c_hits["object"], [0, 3, 4])
+    assert glass.mean() > 0.05 and (c_rgb[glass].sum(axis=1) > 0).mean() > 0.5
+    only8 = np.zeros((w * h, 4), dtype=np.uint8)
+    la = np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
+    pair.gpu.render_frame_raw(view, la, len(la), w, h, (0, 0, w, h), max_depth, None, only8, None)
+    f_rgb, f_c8, _ = pair.gpu.render_frame(view, lights, w, h, max_depth=max_depth)
+    assert np.array_equal(only8, f_c8)
+
+
+def test_specular_slot_table_over_budget_falls_back(gpu_ctx):
+    """With max_depth 8 a refracting pixel owns 255 slots of 32 bytes; a frame with more than 263 000 such pixels
+    exceeds the 2 GiB slot budget and the fused kernel redoes them.  The result must not change."""
+    objs, meshes, lights, view = _glass_scene()
+    objs[0] = rtg.sphere_object((0.0, 0.0, 0.0), 0.6, rtg.material((0.0, 0.0, 0.0), dielectric=(1.0, 1.5)))
+    pair = scenes.Pair(gpu_ctx, objs, meshes)
+    w, h = 1024, 640
+    g_rgb, g_c8, g_hits = pair.gpu.render_frame(view, lights, w, h, max_depth=8)
+    assert (np.isin(g_hits["object"], [0, 3, 4])).sum() > 270000
+    rows = (300, 8)                                           # the oracle checks a strip through the sphere
+    c_rgb, c_c8, c_hits = pair.cpu.render_frame(view, lights, w, h, tile=(0, rows[0], w, rows[1]), max_depth=8)
+    sl = slice(rows[0] * w, (rows[0] + rows[1]) * w)
+    _assert_hits_equal(g_hits[sl], c_hits)
+    assert not scenes.float_bits_differ(g_rgb[sl], c_rgb).any()
+    assert np.abs(g_c8[sl].astype(int) - c_c8.astype(int)).max() <= 1
+
+
 def test_device_f64_div_and_sqrt_are_correctly_rounded(gpu_ctx):
     """The parity argument rests on IEEE-exact device / and sqrt: sweep them through the ray normalisation."""
     import math
