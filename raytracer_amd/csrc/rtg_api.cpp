@@ -53,7 +53,7 @@ struct rtg_mesh {
 struct rtg_scene {
     rtg_ctx *ctx = nullptr;
     DevScene dev{};
-    void *d_objects = nullptr;
+    void *d_objects = nullptr, *d_mesh_objects = nullptr;
     uint32_t max_depth = 0;
     bool any_dielectric = false;   // some material refracts: frames need the specular path tree
     bool has_mesh = false;         // some object is a mesh or patch set: shading is worth doing as passes of the
@@ -100,6 +100,22 @@ bool is_device_pointer(const void *p) {
         return false;
     }
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int scratch_get(rtg_ctx *ctx, const char *name, size_t bytes, void **out);
+
+// Scratch of one persistent launch with `n_out` output slots on `scene`.
+int phased_scratch(rtg_ctx *ctx, const DevScene &ds, uint64_t n_out, PhasedScratch &ps) {
+    int rc;
+    void *v = nullptr;
+    if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &v)) != RTG_OK) return rc;
+    ps.work_counters = (uint32_t *)v;
+    ps.prim_best = nullptr;
+    if (ds.n_mesh_objects != 0 && ds.n_prims != 0) {
+        if ((rc = scratch_get(ctx, "prim_best", n_out * sizeof(rtg_hit), &v)) != RTG_OK) return rc;
+        ps.prim_best = (rtg_hit *)v;
+    }
+    return RTG_OK;
 }
 
 int scratch_get(rtg_ctx *ctx, const char *name, size_t bytes, void **out) {
@@ -627,6 +643,7 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
         DevObject &d = objs[i];
         std::memset(&d, 0, sizeof(d));
         d.kind = o.kind;
+        d.index = (int32_t)i;
         std::memcpy(d.reverse, o.transform.reverse, sizeof(d.reverse));
         std::memcpy(d.forward_norm, o.transform.forward_norm, sizeof(d.forward_norm));
         auto mat = [](const rtg_material &m) {
@@ -682,10 +699,22 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
         if (desc->objects[i].material.has_dielectric || desc->objects[i].material2.has_dielectric) s->any_dielectric = true;
     s->dev.has_patches = 0;
     s->dev.any_f32_ok = 0;
-    s->dev.first_is_mesh = desc->n_objects != 0 && (desc->objects[0].kind == RTG_MESH || desc->objects[0].kind == RTG_PATCHES) &&
-                                   desc->objects[0].mesh->dev.n_nodes != 0
-                               ? 1u
-                               : 0u;
+    {
+        std::vector<DevObject> meshes;
+        uint32_t n_prims = 0;
+        for (const DevObject &d : objs) {
+            if ((d.kind == RTG_MESH || d.kind == RTG_PATCHES) && d.mesh.n_nodes != 0) meshes.push_back(d);
+            if (d.kind == RTG_SPHERE || d.kind == RTG_PLANE) n_prims++;
+        }
+        rc = upload(ctx, meshes.data(), meshes.size() * sizeof(DevObject), &s->d_mesh_objects);
+        if (rc != RTG_OK) {
+            rtg_scene_destroy(s);
+            return rc;
+        }
+        s->dev.mesh_objects = (const DevObject *)s->d_mesh_objects;
+        s->dev.n_mesh_objects = (uint32_t)meshes.size();
+        s->dev.n_prims = n_prims;
+    }
     for (uint32_t i = 0; i < desc->n_objects; i++) {
         const rtg_object &o = desc->objects[i];
         if (o.kind == RTG_PATCHES) s->dev.has_patches = 1;
@@ -700,6 +729,7 @@ void rtg_scene_destroy(rtg_scene *s) {
     if (!s) return;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
     if (s->d_objects) (void)hipFree(s->d_objects);
+    if (s->d_mesh_objects) (void)hipFree(s->d_mesh_objects);
     delete s;
 }
 
@@ -724,10 +754,11 @@ int rtg_render_primary(rtg_scene *scene, const rtg_view *view, uint32_t width, u
     DevScene ds;
     if ((rc = scene_for_launch(scene, tiles * kBlock, ds)) != RTG_OK) return rc;
     if (ctx->traversal == 2) {
-        void *wc = nullptr, *hits = oh.dev;
-        if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
+        void *hits = oh.dev;
+        PhasedScratch ps;
+        if ((rc = phased_scratch(ctx, ds, n, ps)) != RTG_OK) return rc;
         if (op.dev && !hits && (rc = scratch_get(ctx, "points_hits", n * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
-        HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, (uint32_t *)wc, ctx->tune,
+        HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, ps, ctx->tune,
                                                   (rtg_hit *)hits, (rtg_ray_counters *)oc.dev));
         if (op.dev)
             HIP_TRY(ctx, launch_points_primary(ctx->stream, ds, *view, width, height, tile, (const rtg_hit *)hits,
@@ -764,10 +795,11 @@ int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *o
     uint64_t threads = (n_rays + kBlock - 1) / kBlock * kBlock;
     if ((rc = scene_for_launch(scene, threads, ds)) != RTG_OK) return rc;
     if (ctx->traversal == 2) {
-        void *wc = nullptr, *hits = oh.dev;
-        if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
+        void *hits = oh.dev;
+        PhasedScratch ps;
+        if ((rc = phased_scratch(ctx, ds, n_rays, ps)) != RTG_OK) return rc;
         if (op.dev && !hits && (rc = scratch_get(ctx, "points_hits", n_rays * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
-        HIP_TRY(ctx, launch_trace_phased(ctx->stream, ds, (const double *)d_rays, n_rays, (uint32_t *)wc, ctx->tune,
+        HIP_TRY(ctx, launch_trace_phased(ctx->stream, ds, (const double *)d_rays, n_rays, ps, ctx->tune,
                                          (rtg_hit *)hits, (rtg_ray_counters *)oc.dev));
         if (op.dev)
             HIP_TRY(ctx, launch_points_batch(ctx->stream, ds, (const double *)d_rays, n_rays, (const rtg_hit *)hits,
@@ -794,11 +826,11 @@ int shade_wavefront(rtg_ctx *ctx, const DevScene &ds, const rtg_light *d_lights,
     void *occ = nullptr;
     const uint64_t n_shadow = (uint64_t)n_lights * n_points;
     if (n_shadow + n_rays != 0) {
-        void *wc = nullptr;
-        if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
+        PhasedScratch ps;
+        if ((rc = phased_scratch(ctx, ds, n_shadow + n_rays, ps)) != RTG_OK) return rc;
         if ((rc = scratch_get(ctx, "occluders", (size_t)(n_shadow + n_rays) * sizeof(rtg_hit), &occ)) != RTG_OK) return rc;
-        HIP_TRY(ctx, launch_shadow_phased(ctx->stream, ds, d_points, n_points, d_lights, n_lights, d_rays, n_rays,
-                                          (uint32_t *)wc, ctx->tune, (rtg_hit *)occ));
+        HIP_TRY(ctx, launch_shadow_phased(ctx->stream, ds, d_points, n_points, d_lights, n_lights, d_rays, n_rays, ps,
+                                          ctx->tune, (rtg_hit *)occ));
     }
     if (ray_hits) *ray_hits = (const rtg_hit *)occ + n_shadow;
     HIP_TRY(ctx, launch_shade_resolve(ctx->stream, ds, d_lights, n_lights, d_points, n_points, (const rtg_hit *)occ,
@@ -963,12 +995,13 @@ int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *li
         // persistent kernel's building blocks (primary hit ids, point records, shadow rays, resolve); the pixels
         // whose primary hit has a dielectric material -- the only ones with a path tree -- are then redone by the
         // fused kernel.
-        void *wc = nullptr, *pts = nullptr;
-        if ((rc = scratch_get(ctx, "work_counters", (8 * 32 + 16) * sizeof(uint32_t), &wc)) != RTG_OK) return rc;
+        void *pts = nullptr;
+        PhasedScratch ps;
+        if ((rc = phased_scratch(ctx, ds, n, ps)) != RTG_OK) return rc;
         if ((rc = scratch_get(ctx, "frame_points", n * sizeof(rtg_point), &pts)) != RTG_OK) return rc;
         void *hits = oh.dev;
         if (!hits && (rc = scratch_get(ctx, "points_hits", n * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
-        HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, (uint32_t *)wc, ctx->tune,
+        HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, ps, ctx->tune,
                                                   (rtg_hit *)hits, nullptr));
         if (orgb.dev || o8.dev) {
             const bool spec = scene->any_dielectric && max_depth > 1;

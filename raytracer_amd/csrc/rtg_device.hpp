@@ -91,7 +91,7 @@ struct DevMaterial {
 
 struct DevObject {
     int32_t kind;
-    int32_t pad;
+    int32_t index;       // position in the caller's object list (the id reported in hits)
     double reverse[16];
     double forward_norm[9];
     DevMaterial material, material2;
@@ -112,7 +112,11 @@ struct DevScene {
     uint32_t overflow_stride;    // threads the slab was sized for
     uint32_t has_patches;        // some object is a trispline patch set: launch the PATCH kernel variants
     uint32_t any_f32_ok;         // some mesh allows the single-precision box pre-test
-    uint32_t first_is_mesh;      // object 0 is a mesh or patch set with at least one node
+    // The persistent kernel walks only the meshes / patch sets that have nodes (same order, `index` = id); spheres
+    // and planes are answered by a streaming pass and merged in when a ray retires.
+    const DevObject *mesh_objects;
+    uint32_t n_mesh_objects;
+    uint32_t n_prims;            // spheres + planes in `objects`
 };
 
 // ------------------------------------------------------------------- math --

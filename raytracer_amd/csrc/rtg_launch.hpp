@@ -27,11 +27,17 @@ struct PhasedTuning {
     uint32_t pretest = 1;        // single-precision box pre-test with exact fallback
     uint32_t stats = 0;          // diagnostics build: tally steps and lanes per phase
 };
+// Device scratch of one persistent launch: the work counters (8 * 32 + 16 u32) and, for scenes that mix meshes
+// with spheres or planes, one rtg_hit per output slot for the closest sphere / plane hit.
+struct PhasedScratch {
+    uint32_t *work_counters = nullptr;
+    rtg_hit *prim_best = nullptr;
+};
 hipError_t launch_render_primary_phased(hipStream_t stream, const DevScene &s, const rtg_view &view, uint32_t width,
-                                        uint32_t height, rtg_rect tile, uint32_t *work_counters,
+                                        uint32_t height, rtg_rect tile, const PhasedScratch &scratch,
                                         const PhasedTuning &tune, rtg_hit *out_hits, rtg_ray_counters *out_counters);
 hipError_t launch_trace_phased(hipStream_t stream, const DevScene &s, const double *rays6, uint64_t n,
-                               uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits,
+                               const PhasedScratch &scratch, const PhasedTuning &tune, rtg_hit *out_hits,
                                rtg_ray_counters *out_counters);
 // RaycastPoint records rebuilt from hit ids (one lane per ray, streaming): the rays are regenerated from the view
 // or read from the batch.
@@ -44,7 +50,7 @@ hipError_t launch_points_batch(hipStream_t stream, const DevScene &s, const doub
 // the same launch the closest hits of `n_rays` batch rays, out_hits[n_lights * n_points + i].
 hipError_t launch_shadow_phased(hipStream_t stream, const DevScene &s, const rtg_point *points, uint64_t n_points,
                                 const rtg_light *lights, uint32_t n_lights, const double *rays6, uint64_t n_rays,
-                                uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits);
+                                const PhasedScratch &scratch, const PhasedTuning &tune, rtg_hit *out_hits);
 // compute_direct_irrad x diffuse from occluders found by launch_shadow_phased.
 hipError_t launch_shade_resolve(hipStream_t stream, const DevScene &s, const rtg_light *lights, uint32_t n_lights,
                                 const rtg_point *points, uint64_t n, const rtg_hit *occluders, double *rgb_out,

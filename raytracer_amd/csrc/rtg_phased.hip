@@ -357,19 +357,69 @@ __device__ __forceinline__ PreRay make_pre_ray(const Ray &in, float coord_max) {
     return p;
 }
 
+// SceneObject::raycast's `.min()` over the objects' hits (render/scene_object.rs:19-36, ordering
+// render/object.rs:81-99 with real_cmp, math/scalar.rs:46-60): NaN orders below every number and equals NaN.
+__device__ __forceinline__ int real_cmp(double a, double b) {
+    if (is_nan(a)) return is_nan(b) ? 0 : -1;
+    if (is_nan(b)) return 1;
+    return a < b ? -1 : (a > b ? 1 : 0);
+}
+// A later object replaces the best hit only when its time orders strictly below: the first of equals stays.
+__device__ __forceinline__ bool scene_better(bool best_have, double best_t, double t) {
+    return !best_have || real_cmp(t, best_t) < 0;
+}
+
+// Closest hit among the scene's spheres and planes for every item of a source, with every lane busy.  The
+// persistent kernel walks the meshes only and merges this in when a ray retires; in a scene without meshes this
+// pass is the whole answer.  Items without a ray write nothing.
+template <class Source>
+__global__ __launch_bounds__(kBlock) void k_prims(DevScene s, Source src, uint64_t n_items, rtg_hit *out) {
+    uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (item >= n_items) return;
+    Ray ray;
+    uint64_t out_index;
+    if (!src.make(item, ray, out_index)) return;
+    bool have = false;
+    double best_t = kInf;
+    uint32_t best = RTG_NONE;
+    for (uint32_t j = 0; j < s.n_objects; j++) {
+        const DevObject &o = s.objects[j];
+        if (o.kind != RTG_SPHERE && o.kind != RTG_PLANE) continue;
+        Ray in = inner_ray(o, ray);
+        double t = 0.0;
+        bool some = o.kind == RTG_SPHERE
+                        ? sphere_hit_time(ld3(o.sphere_center), o.sphere_radius, in, t)
+                        : plane_hit_time(ld3(o.plane_position), ld3(o.plane_tan1), ld3(o.plane_tan2), in, t);
+        if (some && scene_better(have, best_t, t)) {
+            have = true;
+            best_t = t;
+            best = j;
+        }
+    }
+    uint64_t tb = (uint64_t)__double_as_longlong(have ? best_t : kInf);
+    uint4 v;
+    v.x = best;
+    v.y = RTG_NONE;
+    v.z = (uint32_t)tb;
+    v.w = (uint32_t)(tb >> 32);
+    *reinterpret_cast<uint4 *>(out + out_index) = v;
+}
+
 struct PhasedParams {
     uint32_t tri_min;     // run a TRI step once this many lanes wait for one
     uint32_t obj_min;     // same for the between-objects step
 };
 
 // STATS builds add per-wave step/lane tallies into work_counters[8*kCounterStride ...] (diagnostics only).
-// COUNT builds tally node visits and triangle tests per ray; KEEP builds hold the outer ray in LDS for the objects
-// after the first.  Point records are not built here: a streaming pass rebuilds them from the hit ids
+// The kernel walks the scene's meshes (DevScene::mesh_objects); `prim_best`, when given, holds every item's closest
+// sphere / plane hit, merged in when the ray retires.  COUNT builds tally node visits and triangle tests per ray;
+// KEEP builds (scenes with several meshes) hold the outer ray in LDS for the meshes after the first.  Point records are not built here: a streaming pass rebuilds them from the hit ids
 // (k_points_primary / k_points_batch), with every lane busy.
 template <class Source, bool COUNT, bool PATCH, bool PRE, bool KEEP, bool STATS = false>
 __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
                                                           uint32_t *work_counters, PhasedParams prm,
-                                                          rtg_hit *out_hits, rtg_ray_counters *out_counters) {
+                                                          rtg_hit *out_hits, rtg_ray_counters *out_counters,
+                                                          const rtg_hit *__restrict__ prim_best) {
     uint32_t st_iter = 0, st_node = 0, st_node_l = 0, st_tri = 0, st_tri_l = 0, st_obj = 0, st_obj_l = 0, st_refill = 0;
     uint32_t st_amb = 0, st_amb_l = 0;
     uint64_t tk_node = 0, tk_tri = 0, tk_obj = 0, tk_all = 0, tk0 = 0, tk1 = 0;
@@ -393,14 +443,13 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
     double *cold_lane = cold + threadIdx.x;
     enum { C_BEST_T = 0, C_BEST_ID, C_OUT, C_OX, C_OY, C_OZ, C_DX, C_DY, C_DZ };
 #define COLD(f) cold_lane[(f) * kBlock]
-    // When the scene's first object is a mesh, a wave that takes a new 64-item chunk prepares all 64 rays at once
-    // (ray generation, transform into the mesh's space, pre-test ray) with every lane busy and parks them here
-    // ([field][slot of the wave]); a lane that later needs a ray only copies one slot.
+    // A wave that takes a new 64-item chunk prepares all 64 rays at once (ray generation, transform into the first
+    // mesh's space, pre-test ray) with every lane busy and parks them here ([field][slot of the wave]); a lane that
+    // later needs a ray only copies one slot.
     __shared__ double stage_d[6 * kBlock];
     __shared__ uint32_t stage_u[8 * kBlock];
 #define STG_D(slot, f) stage_d[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
 #define STG_U(slot, f) stage_u[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
-    const bool stage0 = !KEEP || s.first_is_mesh != 0;   // wave-uniform; builds without KEEP only run staged scenes
     const bool need_outer = KEEP;
     Ray in{};                     // ray in the current object's space
     // Builds without the pre-test keep the reciprocal direction for the division-free f64 box test; builds with
@@ -437,19 +486,29 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 tk0 = __builtin_amdgcn_s_memtime();
             }
             // (1) a ray that has seen every object reports its closest hit
-            if (phase == PH_OBJ && has_ray && obj_i >= s.n_objects) {
-                SceneHit sh;
+            if (phase == PH_OBJ && has_ray && obj_i >= s.n_mesh_objects) {
                 uint64_t best_id = (uint64_t)__double_as_longlong(COLD(C_BEST_ID));
                 uint64_t out_index = (uint64_t)__double_as_longlong(COLD(C_OUT));
-                sh.object = (uint32_t)best_id;
-                sh.leaf = (uint32_t)(best_id >> 32);
-                sh.have = sh.object != RTG_NONE;
-                sh.t = COLD(C_BEST_T);
+                uint32_t object = (uint32_t)best_id, leaf = (uint32_t)(best_id >> 32);
+                double t = COLD(C_BEST_T);
+                if (prim_best) {                  // the closest sphere / plane: lower (time, object index) wins
+                    uint4 p = *reinterpret_cast<const uint4 *>(prim_best + out_index);
+                    double tp = __longlong_as_double((long long)(((uint64_t)p.w << 32) | p.z));
+                    if (p.x != RTG_NONE) {
+                        int c = object == RTG_NONE ? -1 : real_cmp(tp, t);
+                        if (c < 0 || (c == 0 && p.x < object)) {
+                            object = p.x;
+                            leaf = RTG_NONE;
+                            t = tp;
+                        }
+                    }
+                }
                 if (out_hits) {
-                    uint64_t tb = __double_as_longlong(sh.have ? sh.t : kInf);
+                    bool have = object != RTG_NONE;
+                    uint64_t tb = __double_as_longlong(have ? t : kInf);
                     uint4 v;
-                    v.x = sh.have ? sh.object : RTG_NONE;
-                    v.y = sh.have ? sh.leaf : RTG_NONE;
+                    v.x = object;
+                    v.y = have ? leaf : RTG_NONE;
                     v.z = (uint32_t)tb;
                     v.w = (uint32_t)(tb >> 32);
                     *reinterpret_cast<uint4 *>(out_hits + out_index) = v;
@@ -472,8 +531,8 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     }
                     chunk_base = (uint64_t)chunk << 6;
                     chunk_left = 64;
-                    if (stage0) {           // every lane prepares one ray of the chunk
-                        const DevObject &o0 = s.objects[0];
+                    {                       // every lane prepares one ray of the chunk
+                        const DevObject &o0 = s.mesh_objects[0];
                         Ray ray;
                         uint64_t out_index;
                         uint32_t flags = 0;
@@ -508,10 +567,10 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 if (phase == PH_OBJ && !has_ray && rank < n_take) {
                     uint32_t slot = (64u - chunk_left) + rank;
                     uint64_t item = chunk_base + slot;
-                    if (stage0) {
+                    {
                         uint32_t flags = STG_U(slot, 7);
                         if (flags & 1u) {
-                            const DevObject &o0 = s.objects[0];
+                            const DevObject &o0 = s.mesh_objects[0];
                             has_ray = true;
                             obj_i = 0;
                             uint64_t out_index = src.slot_of(item);
@@ -556,79 +615,42 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                             }
                             phase = PH_NODE;
                         }
-                    } else if (KEEP) {
-                        Ray ray;
-                        uint64_t out_index;
-                        if (src.make(item, ray, out_index)) {
-                            has_ray = true;
-                            obj_i = 0;
-                            COLD(C_OX) = ray.o.x;
-                            COLD(C_OY) = ray.o.y;
-                            COLD(C_OZ) = ray.o.z;
-                            COLD(C_DX) = ray.d.x;
-                            COLD(C_DY) = ray.d.y;
-                            COLD(C_DZ) = ray.d.z;
-                            COLD(C_OUT) = __longlong_as_double((long long)out_index);
-                            COLD(C_BEST_T) = kInf;
-                            COLD(C_BEST_ID) = __longlong_as_double(-1ll);   // object = leaf = RTG_NONE
-                            ctr.nodes = 0;
-                            ctr.tris = 0;
-                        }
                     }
                 }
                 chunk_left -= n_take;
                 m_need = wave_ballot(phase == PH_OBJ && !has_ray);
             }
             if (exhausted && phase == PH_OBJ && !has_ray) phase = PH_IDLE;   // nothing left for this lane
-            // (3) walk the object list up to the next mesh (spheres and planes are done in place)
-            while (KEEP && phase == PH_OBJ && has_ray && obj_i < s.n_objects) {
-                const DevObject &o = s.objects[obj_i];
+            // (3) a ray that is done with one mesh enters the next one
+            if (KEEP && phase == PH_OBJ && has_ray && obj_i < s.n_mesh_objects) {
+                const DevObject &o = s.mesh_objects[obj_i];
                 {
                     Ray ray{mk(COLD(C_OX), COLD(C_OY), COLD(C_OZ)), mk(COLD(C_DX), COLD(C_DY), COLD(C_DZ))};
                     in = inner_ray(o, ray);
                 }
-                bool some = false;
-                double t = 0.0;
-                if (o.kind == RTG_SPHERE) {
-                    some = sphere_hit_time(ld3(o.sphere_center), o.sphere_radius, in, t);
-                } else if (o.kind == RTG_PLANE) {
-                    some = plane_hit_time(ld3(o.plane_position), ld3(o.plane_tan1), ld3(o.plane_tan2), in, t);
-                } else if ((o.kind == RTG_MESH || o.kind == RTG_PATCHES) && o.mesh.n_nodes != 0) {
-                    slab = (GBytePtr)o.mesh.slab + sizeof(MeshSlabHeader);
-                    end = o.mesh.n_nodes;
-                    cur = 0;
-                    h.has = false;
-                    h.t = kInf;
-                    h.leaf = RTG_NONE;
-                    if (!PRE) {
-                        fast = o.mesh.fast_div_ok != 0 && fast_div_ray_ok(in);
-                        rcp = mk(1.0 / in.d.x, 1.0 / in.d.y, 1.0 / in.d.z);
-                    }
-                    if (PRE) {
-                        pre = o.mesh.f32_ok != 0 && pre_ray_ok(in);
-                        PreRay pr = make_pre_ray(in, o.mesh.coord_max);
-                        r32x = pr.rx;
-                        r32y = pr.ry;
-                        r32z = pr.rz;
-                        np32x = pr.nx;
-                        np32y = pr.ny;
-                        np32z = pr.nz;
-                        e2 = pr.e2;
-                        b32 = __builtin_inff();          // == (float)h.t: an empty holder keeps t = +inf
-                    }
-                    phase = PH_NODE;
-                    break;
+                slab = (GBytePtr)o.mesh.slab + sizeof(MeshSlabHeader);
+                end = o.mesh.n_nodes;
+                cur = 0;
+                h.has = false;
+                h.t = kInf;
+                h.leaf = RTG_NONE;
+                if (!PRE) {
+                    fast = o.mesh.fast_div_ok != 0 && fast_div_ray_ok(in);
+                    rcp = mk(1.0 / in.d.x, 1.0 / in.d.y, 1.0 / in.d.z);
                 }
-                if (some) {
-                    double best_t = COLD(C_BEST_T);
-                    bool best_have = (uint32_t)__double_as_longlong(COLD(C_BEST_ID)) != RTG_NONE;
-                    bool better = !best_have || (!is_nan(best_t) && (is_nan(t) || best_t > t));
-                    if (better) {
-                        COLD(C_BEST_T) = t;
-                        COLD(C_BEST_ID) = __longlong_as_double((long long)(((uint64_t)RTG_NONE << 32) | obj_i));
-                    }
+                if (PRE) {
+                    pre = o.mesh.f32_ok != 0 && pre_ray_ok(in);
+                    PreRay pr = make_pre_ray(in, o.mesh.coord_max);
+                    r32x = pr.rx;
+                    r32y = pr.ry;
+                    r32z = pr.rz;
+                    np32x = pr.nx;
+                    np32y = pr.ny;
+                    np32z = pr.nz;
+                    e2 = pr.e2;
+                    b32 = __builtin_inff();          // == (float)h.t: an empty holder keeps t = +inf
                 }
-                obj_i++;
+                phase = PH_NODE;
             }
             m_node = wave_ballot(phase == PH_NODE);
             m_tri = wave_ballot(phase == PH_TRI);
@@ -750,10 +772,10 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
             if (h.has) {
                 double best_t = COLD(C_BEST_T);
                 bool best_have = (uint32_t)__double_as_longlong(COLD(C_BEST_ID)) != RTG_NONE;
-                bool better = !best_have || (!is_nan(best_t) && (is_nan(h.t) || best_t > h.t));
-                if (better) {
+                if (scene_better(best_have, best_t, h.t)) {
+                    uint32_t id = KEEP ? (uint32_t)s.mesh_objects[obj_i].index : (uint32_t)s.mesh_objects[0].index;
                     COLD(C_BEST_T) = h.t;
-                    COLD(C_BEST_ID) = __longlong_as_double((long long)(((uint64_t)h.leaf << 32) | obj_i));
+                    COLD(C_BEST_ID) = __longlong_as_double((long long)(((uint64_t)h.leaf << 32) | id));
                 }
             }
             obj_i++;
@@ -845,26 +867,43 @@ hipError_t launch_selftest_div(hipStream_t stream, uint64_t seed, uint32_t block
 // ---- launchers -------------------------------------------------------------------------
 template <class Source>
 static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Source &src, uint64_t n_items,
-                                uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits,
-                                rtg_ray_counters *out_counters) {
+                                uint64_t n_out, const PhasedScratch &scratch, const PhasedTuning &tune,
+                                rtg_hit *out_hits, rtg_ray_counters *out_counters) {
     if (n_items == 0) return hipSuccess;
+    // spheres and planes: one streaming pass; it is the whole answer when the scene has no mesh
+    const bool has_mesh = s.n_mesh_objects != 0;
+    rtg_hit *prim_out = has_mesh ? scratch.prim_best : out_hits;
+    if (has_mesh && s.n_prims != 0 && !prim_out) return hipErrorInvalidValue;
+    if ((s.n_prims != 0 || !has_mesh) && prim_out) {
+        dim3 pg((uint32_t)((n_items + kBlock - 1) / kBlock)), pb(kBlock);
+        hipLaunchKernelGGL((k_prims<Source>), pg, pb, 0, stream, s, src, n_items, prim_out);
+    }
+    if (!has_mesh) {
+        if (out_counters) {
+            hipError_t ce = hipMemsetAsync(out_counters, 0, n_out * sizeof(rtg_ray_counters), stream);
+            if (ce != hipSuccess) return ce;
+        }
+        return hipGetLastError();
+    }
+    const rtg_hit *prim_best = s.n_prims != 0 ? scratch.prim_best : nullptr;
+    uint32_t *work_counters = scratch.work_counters;
     hipError_t e = hipMemsetAsync(work_counters, 0, (8 * kCounterStride + 16) * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     uint64_t chunks = (n_items + 63) >> 6;
     uint64_t want = (chunks + 3) / 4;
     uint32_t grid = (uint32_t)(want < tune.max_blocks ? want : tune.max_blocks);
     if (grid == 0) grid = 1;
-    // the outer ray is needed after the first object when there are more objects or when the first object is not a
-    // staged mesh; only then does the dynamic LDS hold it (9 cold fields per lane instead of 3)
+    // the outer ray is needed again when there are several meshes; only then does the dynamic LDS hold it (9 cold
+    // fields per lane instead of 3)
     const bool count = out_counters != nullptr;
-    const bool keep = s.n_objects > 1 || !s.first_is_mesh;
+    const bool keep = s.n_mesh_objects > 1;
     const bool pre = tune.pretest && s.any_f32_ok;
     PhasedParams prm{s.has_patches ? tune.patch_tri_min : tune.tri_min, tune.obj_min};
     const size_t cold_bytes = (size_t)(keep ? 9 : 3) * kBlock * sizeof(double);
     dim3 g(grid), b(kBlock);
 #define RTG_L(C, X, P, K, S)                                                                                      \
     hipLaunchKernelGGL((k_trace_phased<Source, C, X, P, K, S>), g, b, cold_bytes, stream, s, src, n_items,       \
-                       work_counters, prm, out_hits, out_counters)
+                       work_counters, prm, out_hits, out_counters, prim_best)
 #define RTG_L_PRE(C, X, K, S) \
     do {                      \
         if (pre)              \
@@ -895,7 +934,7 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
 }
 
 hipError_t launch_render_primary_phased(hipStream_t stream, const DevScene &s, const rtg_view &view, uint32_t width,
-                                        uint32_t height, rtg_rect tile, uint32_t *work_counters,
+                                        uint32_t height, rtg_rect tile, const PhasedScratch &scratch,
                                         const PhasedTuning &tune, rtg_hit *out_hits,
                                         rtg_ray_counters *out_counters) {
     PrimarySource src;
@@ -905,33 +944,34 @@ hipError_t launch_render_primary_phased(hipStream_t stream, const DevScene &s, c
     src.tile = tile;
     src.tiles_x = (tile.w + 7) / 8;
     uint64_t tiles = (uint64_t)src.tiles_x * ((tile.h + 7) / 8);
-    return launch_phased(stream, s, src, tiles * 64, work_counters, tune, out_hits, out_counters);
+    return launch_phased(stream, s, src, tiles * 64, (uint64_t)tile.w * tile.h, scratch, tune, out_hits, out_counters);
 }
 
 hipError_t launch_trace_phased(hipStream_t stream, const DevScene &s, const double *rays6, uint64_t n,
-                               uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits,
+                               const PhasedScratch &scratch, const PhasedTuning &tune, rtg_hit *out_hits,
                                rtg_ray_counters *out_counters) {
     BatchSource src;
     src.rays6 = rays6;
     src.n = n;
-    return launch_phased(stream, s, src, n, work_counters, tune, out_hits, out_counters);
+    return launch_phased(stream, s, src, n, n, scratch, tune, out_hits, out_counters);
 }
 
 hipError_t launch_shadow_phased(hipStream_t stream, const DevScene &s, const rtg_point *points, uint64_t n_points,
                                 const rtg_light *lights, uint32_t n_lights, const double *rays6, uint64_t n_rays,
-                                uint32_t *work_counters, const PhasedTuning &tune, rtg_hit *out_hits) {
+                                const PhasedScratch &scratch, const PhasedTuning &tune, rtg_hit *out_hits) {
     ShadowSource shadow;
     shadow.points = points;
     shadow.lights = lights;
     shadow.n_points = n_points;
     shadow.n_lights = n_lights;
-    if (n_rays == 0) return launch_phased(stream, s, shadow, n_points * n_lights, work_counters, tune, out_hits, nullptr);
+    if (n_rays == 0)
+        return launch_phased(stream, s, shadow, n_points * n_lights, n_points * n_lights, scratch, tune, out_hits, nullptr);
     ShadowAndBatchSource src;
     src.shadow = shadow;
     src.batch.rays6 = rays6;
     src.batch.n = n_rays;
     src.n_shadow = n_points * n_lights;
-    return launch_phased(stream, s, src, src.n_shadow + n_rays, work_counters, tune, out_hits, nullptr);
+    return launch_phased(stream, s, src, src.n_shadow + n_rays, src.n_shadow + n_rays, scratch, tune, out_hits, nullptr);
 }
 
 } // namespace rtg
