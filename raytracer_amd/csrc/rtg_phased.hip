@@ -451,6 +451,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
 #define STG_D(slot, f) stage_d[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
 #define STG_U(slot, f) stage_u[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
     const bool need_outer = KEEP;
+    const uint32_t first_id = (uint32_t)s.mesh_objects[0].index;   // hit id of the first mesh, read once
     Ray in{};                     // ray in the current object's space
     // Builds without the pre-test keep the reciprocal direction for the division-free f64 box test; builds with
     // it spend those registers on the f32 ray instead and use IEEE division wherever the pre-test cannot decide.
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 double best_t = COLD(C_BEST_T);
                 bool best_have = (uint32_t)__double_as_longlong(COLD(C_BEST_ID)) != RTG_NONE;
                 if (scene_better(best_have, best_t, h.t)) {
-                    uint32_t id = KEEP ? (uint32_t)s.mesh_objects[obj_i].index : (uint32_t)s.mesh_objects[0].index;
+                    uint32_t id = KEEP ? (uint32_t)s.mesh_objects[obj_i].index : first_id;
                     COLD(C_BEST_T) = h.t;
                     COLD(C_BEST_ID) = __longlong_as_double((long long)(((uint64_t)h.leaf << 32) | id));
                 }
