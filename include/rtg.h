@@ -211,7 +211,7 @@ int rtg_ctx_synchronize(rtg_ctx *ctx);
  *               1 = one ray per lane, threaded pre-order tree (skip links, no stack)
  *               2 = persistent phase-scheduled waves over the threaded tree
  *   "tri_min" / "obj_min"               scheduling thresholds of traversal 2 (lanes)
- *   "patch_tri_min"                     tri_min used instead when the scene holds patch sets
+ *   "patch_tri_min"                     lanes waiting for a patch leaf's Newton solve before one runs
  *   "max_blocks"                        persistent grid size of traversal 2
  *   "pretest" 2 = on (default), 1 = off: single-precision box pre-test of traversal 2
  *   "stats" 2 = tally steps per phase in traversal 2 (diagnostics), 1 = off */

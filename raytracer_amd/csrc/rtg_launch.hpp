@@ -21,7 +21,7 @@ hipError_t launch_render_frame(hipStream_t stream, const DevScene &s, const rtg_
 // Persistent phase-scheduled kernels (rtg_phased.hip).
 struct PhasedTuning {
     uint32_t tri_min = 12;
-    uint32_t patch_tri_min = 32;   // same threshold for scenes with patch sets (a patch test is ~20x a triangle test)
+    uint32_t patch_tri_min = 24;   // lanes that must wait for a patch leaf's Newton solve before one runs
     uint32_t obj_min = 8;
     uint32_t max_blocks = 1024;
     uint32_t pretest = 1;        // single-precision box pre-test with exact fallback

@@ -46,7 +46,9 @@ namespace rtg {
 #ifndef RTG_PHASED_WAVES
 #define RTG_PHASED_WAVES 4
 #endif
-enum : uint32_t { PH_IDLE = 0, PH_OBJ = 1, PH_NODE = 2, PH_TRI = 3 };
+enum : uint32_t { PH_IDLE = 0, PH_OBJ = 1, PH_NODE = 2, PH_TRI = 3, PH_DONE = 5, PH_SOLVE = 6 };
+// PH_DONE: traversal of the current mesh finished, reported at the end of the iteration.  PH_SOLVE (patch scenes):
+// the ray hits the flat facet of a patch leaf and waits for the Newton solve, which runs once enough lanes wait.
 
 // Lane mask of a predicate; the intrinsic folds into the compare that produced the predicate.
 __device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -408,6 +410,7 @@ __global__ __launch_bounds__(kBlock) void k_prims(DevScene s, Source src, uint64
 struct PhasedParams {
     uint32_t tri_min;     // run a TRI step once this many lanes wait for one
     uint32_t obj_min;     // same for the between-objects step
+    uint32_t solve_min;   // same for the Newton solve of patch leaves
 };
 
 // STATS builds add per-wave step/lane tallies into work_counters[8*kCounterStride ...] (diagnostics only).
@@ -472,15 +475,28 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
     ctr.nodes = 0;
     ctr.tris = 0;
 
+    // a leaf has been dealt with: next leaf of the node's range (rare), else back to the nodes
+    auto leaf_done = [&]() {
+        bool more = false;
+        if (leaf_cur & 0x80000000u) {    // rare: the owning node (cur - 1) lists several leaves
+            typedef const vu4 __attribute__((address_space(1))) *U4;
+            vu4 tail = ((U4)((GNodePtr)(slab + (uint64_t)end * sizeof(HotNode)) + (cur - 1)))[3];
+            more = (leaf_cur & 0x7FFFFFFFu) + 1 < tail.z + tail.w;
+        }
+        leaf_cur++;
+        phase = more ? PH_TRI : (cur >= end ? PH_DONE : PH_NODE);
+    };
+
     for (;;) {
         if (STATS) st_iter++;
         uint64_t m_node = wave_ballot(phase == PH_NODE);
         uint64_t m_tri = wave_ballot(phase == PH_TRI);
         uint64_t m_obj = wave_ballot(phase == PH_OBJ);
-        if ((m_node | m_tri | m_obj) == 0) break;   // every lane is done and no chunk is left
+        uint64_t m_solve = PATCH ? wave_ballot(phase == PH_SOLVE) : 0;
+        if ((m_node | m_tri | m_obj | m_solve) == 0) break;   // every lane is done and no chunk is left
 
         // ---- between objects: finish the ray, fetch the next one, enter the next object -------
-        if (m_obj != 0 && ((uint32_t)__popcll(m_obj) >= prm.obj_min || (m_node | m_tri) == 0)) {
+        if (m_obj != 0 && ((uint32_t)__popcll(m_obj) >= prm.obj_min || (m_node | m_tri | m_solve) == 0)) {
             if (STATS) {
                 st_obj++;
                 st_obj_l += (uint32_t)__popcll(m_obj);
@@ -726,7 +742,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                         leaf_cur = t.z | 0x80000000u;
                     }
                 }
-                if (phase == PH_NODE && cur >= end) phase = PH_OBJ + 4;   // traversal finished (resolved below)
+                if (phase == PH_NODE && cur >= end) phase = PH_DONE;   // traversal finished (resolved below)
             }
             m_tri = wave_ballot(phase == PH_TRI);
             if (STATS) tk_node += __builtin_amdgcn_s_memtime() - tk0;
@@ -745,31 +761,47 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 load_tri_g((GTriPtr)(slab + (uint64_t)end * (sizeof(HotNode) + sizeof(DevNode))) + leaf, v0, v1, v2);
                 double t;
                 bool some;
-                const MeshSlabHeader *hdr = (const MeshSlabHeader *)(const uint8_t *)(slab - sizeof(MeshSlabHeader));
-                if (PATCH && hdr->patches) {
-                    PatchHit ph;
-                    some = patch_leaf_hit<false>(hdr->patches, hdr->leaf_info + leaf, hdr->newton_steps, v0, v1, v2, in, ph);
-                    t = ph.tau;
+                bool solve = false;
+                if (PATCH && ((const MeshSlabHeader *)(const uint8_t *)(slab - sizeof(MeshSlabHeader)))->patches) {
+                    // patch leaf: only rays that hit the flat facet go on to the Newton solve, in a step of its own
+                    V3 bary;
+                    solve = tri_hit_full(v0, v1, v2, in, t, bary);
+                    some = false;
                 } else {
                     some = tri_hit_time_signs(v0, v1, v2, in, t);
                 }
-                holder_add(h, some, t, leaf);
-                if (PRE) b32 = (float)h.t;       // an empty holder keeps t = +inf
                 if (COUNT) ctr.tris++;
-                bool more = false;
-                if (leaf_cur & 0x80000000u) {    // rare: the owning node (cur - 1) lists several leaves
-                    typedef const vu4 __attribute__((address_space(1))) *U4;
-                    vu4 tail = ((U4)((GNodePtr)(slab + (uint64_t)end * sizeof(HotNode)) + (cur - 1)))[3];
-                    more = leaf + 1 < tail.z + tail.w;
+                if (solve) {
+                    phase = PH_SOLVE;
+                } else {
+                    holder_add(h, some, t, leaf);
+                    if (PRE) b32 = (float)h.t;       // an empty holder keeps t = +inf
+                    leaf_done();
                 }
-                leaf_cur++;
-                if (!more) phase = cur >= end ? PH_OBJ + 4 : PH_NODE;
             }
             if (STATS) tk_tri += __builtin_amdgcn_s_memtime() - tk0;
         }
 
+        // ---- patch scenes: Newton solve for the lanes whose ray hits its leaf's facet ---------
+        if (PATCH) {
+            m_solve = wave_ballot(phase == PH_SOLVE);
+            if (m_solve != 0 && ((uint32_t)__popcll(m_solve) >= prm.solve_min || wave_ballot(phase == PH_NODE) == 0)) {
+                if (phase == PH_SOLVE) {
+                    V3 v0, v1, v2;
+                    const uint32_t leaf = leaf_cur & 0x7FFFFFFFu;
+                    load_tri_g((GTriPtr)(slab + (uint64_t)end * (sizeof(HotNode) + sizeof(DevNode))) + leaf, v0, v1, v2);
+                    const MeshSlabHeader *hdr = (const MeshSlabHeader *)(const uint8_t *)(slab - sizeof(MeshSlabHeader));
+                    PatchHit ph;
+                    bool some = patch_leaf_hit<false>(hdr->patches, hdr->leaf_info + leaf, hdr->newton_steps, v0, v1, v2, in, ph);
+                    holder_add(h, some, ph.tau, leaf);
+                    if (PRE) b32 = (float)h.t;
+                    leaf_done();
+                }
+            }
+        }
+
         // ---- a finished traversal reports to the scene-level minimum ------------------------
-        if (phase == PH_OBJ + 4) {
+        if (phase == PH_DONE) {
             if (h.has) {
                 double best_t = COLD(C_BEST_T);
                 bool best_have = (uint32_t)__double_as_longlong(COLD(C_BEST_ID)) != RTG_NONE;
@@ -899,7 +931,7 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     const bool count = out_counters != nullptr;
     const bool keep = s.n_mesh_objects > 1;
     const bool pre = tune.pretest && s.any_f32_ok;
-    PhasedParams prm{s.has_patches ? tune.patch_tri_min : tune.tri_min, tune.obj_min};
+    PhasedParams prm{tune.tri_min, tune.obj_min, tune.patch_tri_min};
     const size_t cold_bytes = (size_t)(keep ? 9 : 3) * kBlock * sizeof(double);
     dim3 g(grid), b(kBlock);
 #define RTG_L(C, X, P, K, S)                                                                                      \
