@@ -496,7 +496,13 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
         if ((m_node | m_tri | m_obj | m_solve) == 0) break;   // every lane is done and no chunk is left
 
         // ---- between objects: finish the ray, fetch the next one, enter the next object -------
-        if (m_obj != 0 && ((uint32_t)__popcll(m_obj) >= prm.obj_min || (m_node | m_tri | m_solve) == 0)) {
+        // Thresholds scale with the lanes that still have a ray: once the work queue is dry a wave drains with few
+        // lanes, and making those wait for a full-size batch would only serialise them.
+        const uint32_t live = (uint32_t)__popcll(m_node | m_tri | m_solve);
+        const uint32_t tri_thr = exhausted ? (live * prm.tri_min + 63u) >> 6 : prm.tri_min;
+        const uint32_t solve_thr = exhausted ? (live * prm.solve_min + 63u) >> 6 : prm.solve_min;
+        const uint32_t obj_thr = exhausted ? 1u : prm.obj_min;
+        if (m_obj != 0 && ((uint32_t)__popcll(m_obj) >= obj_thr || (m_node | m_tri | m_solve) == 0)) {
             if (STATS) {
                 st_obj++;
                 st_obj_l += (uint32_t)__popcll(m_obj);
@@ -749,7 +755,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
         }
 
         // ---- one triangle per waiting lane ----------------------------------------------
-        if (m_tri != 0 && ((uint32_t)__popcll(m_tri) >= prm.tri_min || wave_ballot(phase == PH_NODE) == 0)) {
+        if (m_tri != 0 && ((uint32_t)__popcll(m_tri) >= tri_thr || wave_ballot(phase == PH_NODE) == 0)) {
             if (STATS) {
                 st_tri++;
                 st_tri_l += (uint32_t)__popcll(m_tri);
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
         // ---- patch scenes: Newton solve for the lanes whose ray hits its leaf's facet ---------
         if (PATCH) {
             m_solve = wave_ballot(phase == PH_SOLVE);
-            if (m_solve != 0 && ((uint32_t)__popcll(m_solve) >= prm.solve_min || wave_ballot(phase == PH_NODE) == 0)) {
+            if (m_solve != 0 && ((uint32_t)__popcll(m_solve) >= solve_thr || wave_ballot(phase == PH_NODE) == 0)) {
                 if (phase == PH_SOLVE) {
                     V3 v0, v1, v2;
                     const uint32_t leaf = leaf_cur & 0x7FFFFFFFu;
