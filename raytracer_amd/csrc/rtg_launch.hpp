@@ -20,9 +20,9 @@ hipError_t launch_render_frame(hipStream_t stream, const DevScene &s, const rtg_
 
 // Persistent phase-scheduled kernels (rtg_phased.hip).
 struct PhasedTuning {
-    uint32_t tri_min = 14;
+    uint32_t tri_min = 20;
     uint32_t patch_tri_min = 24;   // lanes that must wait for a patch leaf's Newton solve before one runs
-    uint32_t obj_min = 6;
+    uint32_t obj_min = 4;
     uint32_t max_blocks = 1024;
     uint32_t pretest = 1;        // single-precision box pre-test with exact fallback
     uint32_t stats = 0;          // diagnostics build: tally steps and lanes per phase

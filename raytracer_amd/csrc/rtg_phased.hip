@@ -43,6 +43,9 @@
 
 namespace rtg {
 
+#ifndef RTG_NODE_BURST
+#define RTG_NODE_BURST 16
+#endif
 #ifndef RTG_PHASED_WAVES
 #define RTG_PHASED_WAVES 4
 #endif
@@ -680,8 +683,9 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
             if (STATS) tk_obj += __builtin_amdgcn_s_memtime() - tk0;
         }
 
-        // ---- one box test per lane ---------------------------------------------------
-        if (m_node != 0) {
+        // ---- one box test per lane (twice while nothing else is due) --------------------------
+#pragma unroll 1
+        for (int rep = 0; rep < RTG_NODE_BURST && m_node != 0; rep++) {
             if (STATS) {
                 st_node++;
                 st_node_l += (uint32_t)__popcll(m_node);
@@ -752,6 +756,9 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
             }
             m_tri = wave_ballot(phase == PH_TRI);
             if (STATS) tk_node += __builtin_amdgcn_s_memtime() - tk0;
+            // go round again until a triangle step is due (finished lanes wait for the end of the burst)
+            m_node = wave_ballot(phase == PH_NODE);
+            if ((uint32_t)__popcll(m_tri) >= tri_thr) break;
         }
 
         // ---- one triangle per waiting lane ----------------------------------------------
