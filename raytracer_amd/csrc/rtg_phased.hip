@@ -43,6 +43,9 @@
 
 namespace rtg {
 
+#ifndef RTG_ROUNDS
+#define RTG_ROUNDS 32
+#endif
 #ifndef RTG_NODE_BURST
 #define RTG_NODE_BURST 16
 #endif
@@ -683,7 +686,12 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
             if (STATS) tk_obj += __builtin_amdgcn_s_memtime() - tk0;
         }
 
-        // ---- one box test per lane (twice while nothing else is due) --------------------------
+        // ---- traversal rounds: box tests in bursts, then the triangle step that ended the burst; the wave stays in
+        // this inner loop until enough lanes wait between objects (leaving it is what costs: the outer iteration
+        // re-evaluates every phase mask and merges the per-lane flags)
+#pragma unroll 1
+        for (int round = 0; round < RTG_ROUNDS; round++) {
+        // ---- one box test per lane, repeated until a triangle step is due ----------------------
 #pragma unroll 1
         for (int rep = 0; rep < RTG_NODE_BURST && m_node != 0; rep++) {
             if (STATS) {
@@ -812,6 +820,14 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                 }
             }
         }
+
+        m_node = wave_ballot(phase == PH_NODE);
+        m_tri = wave_ballot(phase == PH_TRI);
+        if (PATCH) m_solve = wave_ballot(phase == PH_SOLVE);
+        if ((uint32_t)__popcll(wave_ballot(phase == PH_DONE || phase == PH_OBJ)) >= obj_thr ||
+            (m_node | m_tri | m_solve) == 0)
+            break;
+        }   // traversal rounds
 
         // ---- a finished traversal reports to the scene-level minimum ------------------------
         if (phase == PH_DONE) {
