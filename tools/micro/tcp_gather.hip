@@ -34,6 +34,11 @@ __global__ __launch_bounds__(256, 4) void k_gather(const vu4 *__restrict__ recs,
             uint32_t idx = (st >> 8) % n_recs;
             vu4 a = recs[(size_t)idx * 2];
             acc ^= a;
+        } else if (MODE == 4) {     // dependent chain: the next record index comes out of the loaded record (two loads)
+            uint32_t idx = (st >> 8) % n_recs;
+            vu4 a = recs[(size_t)idx * 2], b = recs[(size_t)idx * 2 + 1];
+            acc ^= a ^ b;
+            st = st * 1664525u + (a.x ^ b.y);
         } else {                    // quad-cooperative 64-byte records: four lanes read one record's four quarters
             st_pair = (st_pair * 1664525u + 1013904223u);
             uint32_t base = ((gid & ~3u) * 2654435761u + 12345u) + i * 40503u;
@@ -59,20 +64,22 @@ int main() {
     (void)hipEventCreate(&e1);
     const uint32_t sizes[3] = {256u, 65536u, 2u << 20};   // 8 KB (L1), 2 MB (L2), 64 MB (MALL)
     for (int si = 0; si < 3; si++)
-    for (int mode = 0; mode < 4; mode++) {
+    for (int mode = 0; mode < 5; mode++) {
         const uint32_t n_recs = sizes[si];
         for (int rep = 0; rep < 2; rep++) {
             (void)hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(k_gather<0>, dim3(1024), dim3(256), 0, 0, d, n_recs, iters, out);
             if (mode == 1) hipLaunchKernelGGL(k_gather<1>, dim3(1024), dim3(256), 0, 0, d, n_recs, iters, out);
             if (mode == 2) hipLaunchKernelGGL(k_gather<2>, dim3(1024), dim3(256), 0, 0, d, n_recs, iters, out);
+            if (mode == 4) hipLaunchKernelGGL(k_gather<4>, dim3(1024), dim3(256), 0, 0, d, n_recs, iters, out);
             if (mode == 3) hipLaunchKernelGGL(k_gather<3>, dim3(1024), dim3(256), 0, 0, d, n_recs, iters, out);
             (void)hipEventRecord(e1);
             (void)hipEventSynchronize(e1);
             float ms;
             (void)hipEventElapsedTime(&ms, e0, e1);
-            double lane_loads = 1024.0 * 256 * iters * (mode == 0 || mode == 1 ? 2 : 1);
+            double lane_loads = 1024.0 * 256 * iters * (mode == 0 || mode == 1 || mode == 4 ? 2 : 1);
             if (rep == 1)
+                if (mode == 4) printf("          dependent chain: %.0f clk per step (2.4 GHz)\n", ms * 1e-3 * 2.4e9 / iters);
                 printf("%8u records, mode %d: %.3f ms, %.2f lane-loads/clk/CU (2.4 GHz, 256 CUs), %.1f GB/s\n", n_recs, mode, ms,
                        lane_loads / (ms * 1e-3) / 2.4e9 / 256, lane_loads * 16 / (ms * 1e-3) / 1e9);
         }
