@@ -460,7 +460,11 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
 #define STG_D(slot, f) stage_d[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
 #define STG_U(slot, f) stage_u[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
     const bool need_outer = KEEP;
-    const uint32_t first_id = (uint32_t)s.mesh_objects[0].index;   // hit id of the first mesh, read once
+    // the first mesh's constants, read once per wave
+    const uint32_t first_id = (uint32_t)s.mesh_objects[0].index;
+    const GBytePtr first_slab = (GBytePtr)s.mesh_objects[0].mesh.slab + sizeof(MeshSlabHeader);
+    const uint32_t first_end = s.mesh_objects[0].mesh.n_nodes;
+    const bool first_fast_ok = s.mesh_objects[0].mesh.fast_div_ok != 0;
     Ray in{};                     // ray in the current object's space
     // Builds without the pre-test keep the reciprocal direction for the division-free f64 box test; builds with
     // it spend those registers on the f32 ray instead and use IEEE division wherever the pre-test cannot decide.
@@ -599,7 +603,6 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     {
                         uint32_t flags = STG_U(slot, 7);
                         if (flags & 1u) {
-                            const DevObject &o0 = s.mesh_objects[0];
                             has_ray = true;
                             obj_i = 0;
                             uint64_t out_index = src.slot_of(item);
@@ -621,14 +624,14 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                             // straight into the first object's tree
                             in = Ray{mk(STG_D(slot, 0), STG_D(slot, 1), STG_D(slot, 2)),
                                      mk(STG_D(slot, 3), STG_D(slot, 4), STG_D(slot, 5))};
-                            slab = (GBytePtr)o0.mesh.slab + sizeof(MeshSlabHeader);
-                            end = o0.mesh.n_nodes;
+                            slab = first_slab;
+                            end = first_end;
                             cur = 0;
                             h.has = false;
                             h.t = kInf;
                             h.leaf = RTG_NONE;
                             if (!PRE) {
-                                fast = o0.mesh.fast_div_ok != 0 && fast_div_ray_ok(in);
+                                fast = first_fast_ok && fast_div_ray_ok(in);
                                 rcp = mk(1.0 / in.d.x, 1.0 / in.d.y, 1.0 / in.d.z);
                             }
                             if (PRE) {
