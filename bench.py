@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- Mrays/s of the GPU ray-cast path on the 1M-triangle BVH scene (BASELINE config 2).
+"""bench.py -- Mrays/s of the GPU ray-cast path on the 1M-triangle BVH scene.
 
 A step is one pass of the hot path over one batch: a full 1920x1080 primary-ray frame (ray generation +
 BVH traversal + ray/triangle intersection + closest hit -> 16-byte hit records) against the 1 000 000-triangle

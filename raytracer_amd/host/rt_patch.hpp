@@ -5,7 +5,7 @@
 // SplineTrispline -> Trispline conversion chain (trispline.rs:68-134) and patch
 // evaluation (trispline.rs:161-181), plus what the reference lacks: tessellation
 // of patches into the flat facets the BVH is built over, and a seeded terrain
-// of patches for BASELINE config 3.
+// of patches for the trispline benchmark configuration.
 #pragma once
 #include <cstdint>
 #include <vector>

@@ -1,4 +1,4 @@
-"""GPU, full size: BASELINE config 2 -- 1M-triangle BVH, 1920x1080 primary rays, bit-exact hit-ID image."""
+"""GPU, full size: the 1M-triangle BVH configuration, 1920x1080 primary rays, bit-exact hit-ID image."""
 import numpy as np
 import pytest
 

@@ -133,7 +133,7 @@ def test_gpu_patch_scene_matches_oracle(gpu_ctx, traversal):
 
 @pytest.mark.gpu
 def test_gpu_config3_patches_at_4k(gpu_ctx):
-    """BASELINE config 3: trispline surface scene, 3840x2160 primary rays (1M facets behind 15 500 patches)."""
+    """The trispline surface configuration, 3840x2160 primary rays (1M facets behind 15 500 patches)."""
     patches = rtg.patch_terrain(125, 62, seed=7, scale=100.0)
     pm = rtg.HostPatchMesh(patches, k=8, newton_steps=5)
     assert pm.bvh.n_leaves == 125 * 62 * 2 * 64
