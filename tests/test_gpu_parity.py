@@ -438,6 +438,51 @@ def test_specular_slot_table_over_budget_falls_back(gpu_ctx):
     assert np.abs(g_c8[sl].astype(int) - c_c8.astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_scenes_with_special_values(gpu_ctx, seed):
+    """Random small scenes (meshes under random affine transforms, spheres, planes, in random order) traced with rays
+    that carry special values: zero, denormal, huge and tiny components, infinities and NaNs in origins and
+    directions, origins exactly on geometry.  Whatever the reference's arithmetic yields for them -- including NaN
+    hit times -- the GPU must yield too."""
+    rng = np.random.default_rng(1000 + seed)
+    objs, meshes = [], {}
+    for i in range(int(rng.integers(1, 6))):
+        kind = rng.integers(0, 3)
+        m = np.eye(4)
+        m[:3, :3] = rng.normal(size=(3, 3)) * rng.choice([1e-3, 0.3, 1.0, 40.0])
+        m[:3, 3] = rng.normal(size=3)
+        xf = rtg.transform_from_forward(m) if rng.random() < 0.7 else None
+        if kind == 0:
+            n = int(rng.integers(1, 400))
+            tris = rng.normal(size=(n, 1, 3)) * 2 + rng.normal(size=(n, 3, 3)) * rng.choice([0.05, 0.5])
+            if rng.random() < 0.3:
+                tris[: n // 4, :, int(rng.integers(0, 3))] = np.round(tris[: n // 4, :1, 0], 1)   # axis-aligned flats
+            if rng.random() < 0.3:
+                tris[n // 2:] *= 2.0 ** int(rng.integers(-60, 60))                                   # outside the f32 window
+            objs.append(rtg.mesh_object(None, rtg.material((0.5, 0.5, 0.5)), xf))
+            meshes[i] = rtg.HostBvh(np.ascontiguousarray(tris))
+        elif kind == 1:
+            objs.append(rtg.sphere_object(tuple(rng.normal(size=3)), float(abs(rng.normal()) + 0.01), rtg.material((1, 1, 1)), xf))
+        else:
+            objs.append(rtg.plane_object(tuple(rng.normal(size=3)), tuple(rng.normal(size=3)), tuple(rng.normal(size=3)),
+                                         rtg.material((1, 1, 1)), rtg.material((0.1, 0.1, 0.1)), xf))
+    pair = scenes.Pair(gpu_ctx, objs, meshes)
+    n = 4000
+    rays = np.concatenate([rng.normal(size=(n, 3)) * 3, rng.normal(size=(n, 3))], axis=1)
+    special = np.array([0.0, -0.0, 5e-324, 1e-310, 1e-200, 1e200, 1e308, -1e308, np.inf, -np.inf, np.nan, 1.0, -1.0, 2.0 ** -41, 2.0 ** 41])
+    sel = rng.random(size=rays.shape) < 0.08
+    rays[sel] = rng.choice(special, size=int(sel.sum()))
+    rays[: n // 10, 3:] = np.eye(3)[rng.integers(0, 3, size=n // 10)] * rng.choice([-1.0, 1.0], size=(n // 10, 1))
+    for traversal in TRAVERSALS:
+        gpu_ctx.set_option("traversal", traversal)
+        g_hits, g_pts, g_ctr = pair.gpu.trace(rays, points=True, counters=True)
+        c_hits, c_pts, c_ctr = pair.cpu.trace(rays, points=True, counters=True)
+        _assert_hits_equal(g_hits, c_hits)
+        _assert_points_equal(g_pts, c_pts)
+        assert np.array_equal(g_ctr, c_ctr)
+    gpu_ctx.set_option("traversal", 2)
+
+
 def test_device_f64_div_and_sqrt_are_correctly_rounded(gpu_ctx):
     """The parity argument rests on IEEE-exact device / and sqrt: sweep them through the ray normalisation."""
     import math
