@@ -60,7 +60,11 @@ enum : uint32_t { PH_IDLE = 0, PH_OBJ = 1, PH_NODE = 2, PH_TRI = 3, PH_DONE = 5,
 __device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // ---- ray sources ------------------------------------------------------------------
+// Every source also names the time below which a hit ends the query early (stop_time): -inf for closest-hit
+// queries; a shadow ray only has to know whether anything lies before the light.
 struct PrimarySource {
+    static constexpr bool kEarlyStop = false;
+    __device__ __forceinline__ double stop_time(uint64_t) const { return -kInf; }
     rtg_view view;
     uint32_t width, height;
     rtg_rect tile;
@@ -90,6 +94,8 @@ struct PrimarySource {
     }
 };
 struct BatchSource {
+    static constexpr bool kEarlyStop = false;
+    __device__ __forceinline__ double stop_time(uint64_t) const { return -kInf; }
     const double *rays6;
     uint64_t n;
     __device__ __forceinline__ uint64_t slot_of(uint64_t item) const { return item; }
@@ -107,10 +113,21 @@ struct BatchSource {
 // l * n_points + p is light l seen from point p; items without a query (no hit at p, light behind the surface)
 // produce no ray and leave their output slot untouched.
 struct ShadowSource {
+    static constexpr bool kEarlyStop = true;
     const rtg_point *points;
     const rtg_light *lights;
     uint64_t n_points;
     uint32_t n_lights;
+    // compute_direct_irrad only asks whether the closest hit lies before the light (`occ.t < dis`,
+    // render/renderer.rs:184-205).  The first accepted hit below `dis` settles that: the reference's own traversal
+    // meets the same hit in the same state, and its final minimum can only be lower.
+    __device__ __forceinline__ double stop_time(uint64_t item) const {
+        uint64_t l = item / n_points, p = item - l * n_points;
+        const rtg_point &pt = points[p];
+        ShadowQuery q;
+        (void)shadow_query(lights[l], ld3(pt.position), ld3(pt.inter_normal), q);
+        return q.dis;
+    }
     __device__ __forceinline__ uint64_t slot_of(uint64_t item) const { return item; }
     __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
         uint64_t l = item / n_points, p = item - l * n_points;
@@ -129,9 +146,13 @@ struct ShadowSource {
 // n_shadow are ShadowSource items, the rest are batch rays; the output slot is the item index, so the hit buffer is
 // the occluder table followed by the batch hits.
 struct ShadowAndBatchSource {
+    static constexpr bool kEarlyStop = true;
     ShadowSource shadow;
     BatchSource batch;
     uint64_t n_shadow;
+    __device__ __forceinline__ double stop_time(uint64_t item) const {
+        return item < n_shadow ? shadow.stop_time(item) : -kInf;
+    }
     __device__ __forceinline__ uint64_t slot_of(uint64_t item) const { return item; }
     __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
         bool ok = item < n_shadow ? shadow.make(item, ray, out_index) : batch.make(item - n_shadow, ray, out_index);
@@ -456,7 +477,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
     // mesh's space, pre-test ray) with every lane busy and parks them here ([field][slot of the wave]); a lane that
     // later needs a ray only copies one slot.
     __shared__ double stage_d[6 * kBlock];
-    __shared__ uint32_t stage_u[8 * kBlock];
+    __shared__ uint32_t stage_u[(Source::kEarlyStop ? 10 : 8) * kBlock];
 #define STG_D(slot, f) stage_d[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
 #define STG_U(slot, f) stage_u[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
     const bool need_outer = KEEP;
@@ -478,6 +499,8 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
     uint32_t leaf_cur = 0;        // next leaf to test; bit 31: the node (cur - 1) has several leaves, its range ends the TRI phase
     GBytePtr slab = nullptr;      // the current mesh's hot-node array (slab + 64); everything else is an offset
     bool pre = false;             // this ray/mesh pair may use the single-precision pre-test
+    double t_stop = -kInf;        // sources with kEarlyStop: a held hit below this time ends the query
+    bool stopped = false;
     // single-precision ray for the pre-test: reciprocal direction, -(origin * reciprocal), error bound, and the
     // holder's bound rounded to f32
     float r32x = 0, r32y = 0, r32z = 0, np32x = 0, np32y = 0, np32z = 0, e2 = 0, b32 = 0;
@@ -591,6 +614,11 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                             }
                         }
                         STG_U(threadIdx.x & 63u, 7) = flags;
+                        if (Source::kEarlyStop && flags != 0) {
+                            uint64_t tb = (uint64_t)__double_as_longlong(src.stop_time(chunk_base + (threadIdx.x & 63u)));
+                            STG_U(threadIdx.x & 63u, 8) = (uint32_t)tb;
+                            STG_U(threadIdx.x & 63u, 9) = (uint32_t)(tb >> 32);
+                        }
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
@@ -605,6 +633,10 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                         if (flags & 1u) {
                             has_ray = true;
                             obj_i = 0;
+                            if (Source::kEarlyStop) {
+                                t_stop = __longlong_as_double((long long)(((uint64_t)STG_U(slot, 9) << 32) | STG_U(slot, 8)));
+                                stopped = false;
+                            }
                             uint64_t out_index = src.slot_of(item);
                             if (need_outer) {
                                 Ray ray;
@@ -801,6 +833,10 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     holder_add(h, some, t, leaf);
                     if (PRE) b32 = (float)h.t;       // an empty holder keeps t = +inf
                     leaf_done();
+                    if (Source::kEarlyStop && h.has && h.t < t_stop) {
+                        stopped = true;
+                        phase = PH_DONE;
+                    }
                 }
             }
             if (STATS) tk_tri += __builtin_amdgcn_s_memtime() - tk0;
@@ -820,6 +856,10 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     holder_add(h, some, ph.tau, leaf);
                     if (PRE) b32 = (float)h.t;
                     leaf_done();
+                    if (Source::kEarlyStop && h.has && h.t < t_stop) {
+                        stopped = true;
+                        phase = PH_DONE;
+                    }
                 }
             }
         }
@@ -843,7 +883,7 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
                     COLD(C_BEST_ID) = __longlong_as_double((long long)(((uint64_t)h.leaf << 32) | id));
                 }
             }
-            obj_i++;
+            obj_i = (Source::kEarlyStop && stopped) ? s.n_mesh_objects : obj_i + 1;
             phase = PH_OBJ;
         }
     }
