@@ -244,6 +244,20 @@ void rtg_mesh_destroy(rtg_mesh *mesh);
  * RTG_PATCHES); `bvh` is the flattened tree over the facets, built like any
  * mesh.  No reference counterpart for the intersection (see rtg_patch_set). */
 int rtg_mesh_create_patches(rtg_ctx *ctx, const rtg_bvh *bvh, const rtg_patch_set *patches, rtg_mesh **out);
+/* Builds the tree on the GPU: replaces `BvhForest::new(&tris).subdivide()` followed by `Bvh::new`
+ * (src/tree/bvh.rs:48-58,80-106; src/tree/bvh_subdivide.rs:8-43).  The tree is the one those functions produce,
+ * node for node (same splits, same leaf order, same boxes), so hit leaf indices mean the same as with a
+ * host-flattened tree; `rtg_mesh_read_bvh` returns it.  `triangles` (and the optional `vertex_normals`,
+ * n x 3 x 3 doubles) may be host or device memory and are not retained.  Every vertex must be finite (the
+ * reference panics on a NaN sort key, bvh_subdivide.rs:28): RTG_E_INVALID otherwise. */
+int rtg_mesh_build(rtg_ctx *ctx, const rtg_tri *triangles, uint64_t n_triangles, const double *vertex_normals,
+                   rtg_mesh **out);
+/* Node and leaf counts, root index (`Bvh::root`) and depth of a mesh's flattened tree; any pointer may be NULL. */
+int rtg_mesh_sizes(const rtg_mesh *mesh, uint64_t *n_nodes, uint64_t *n_leaves, uint32_t *root, uint32_t *depth);
+/* Copies a mesh's flattened tree back to host arrays sized by rtg_mesh_sizes: `nodes` in the order of
+ * `Bvh::nodes`, `leaves` in the order of `Bvh::leaves` (src/tree/bvh.rs:20-24), `leaf_source[l]` = index of leaf
+ * l's triangle in the array given to rtg_mesh_build (the identity for rtg_mesh_create).  Any pointer may be NULL. */
+int rtg_mesh_read_bvh(const rtg_mesh *mesh, rtg_bvh_node *nodes, rtg_tri *leaves, uint32_t *leaf_source);
 /* `Bvh::bounds` (src/tree/bvh.rs:134-136): lo[3], hi[3] of the root. */
 int rtg_mesh_bounds(const rtg_mesh *mesh, double out_lo_hi[6]);
 

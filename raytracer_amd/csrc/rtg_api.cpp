@@ -7,6 +7,7 @@
 // point that needs one fails with RTG_E_NODEVICE / RTG_E_HIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -45,6 +46,7 @@ struct rtg_mesh {
     DevMesh dev{};
     void *d_nodes = nullptr, *d_slab = nullptr, *d_normals = nullptr;
     void *d_patches = nullptr, *d_leaf_info = nullptr;
+    void *d_leaf_source = nullptr;   // built on the device: the caller's triangle index of every leaf
     bool is_patches = false;
     double bounds[6] = {0, 0, 0, 0, 0, 0};
     uint64_t n_leaves = 0;
@@ -578,6 +580,7 @@ void rtg_mesh_destroy(rtg_mesh *m) {
     if (m->d_normals) (void)hipFree(m->d_normals);
     if (m->d_patches) (void)hipFree(m->d_patches);
     if (m->d_leaf_info) (void)hipFree(m->d_leaf_info);
+    if (m->d_leaf_source) (void)hipFree(m->d_leaf_source);
     delete m;
 }
 
@@ -619,6 +622,153 @@ int rtg_mesh_create_patches(rtg_ctx *ctx, const rtg_bvh *bvh, const rtg_patch_se
     m->dev.leaf_info = (const rtg_patch_leaf *)m->d_leaf_info;
     m->dev.newton_steps = ps->newton_steps;
     *out = m;
+    return RTG_OK;
+}
+
+int rtg_mesh_build(rtg_ctx *ctx, const rtg_tri *triangles, uint64_t n_triangles, const double *vertex_normals,
+                   rtg_mesh **out) {
+    if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
+    if (!out || (n_triangles && !triangles)) return fail(ctx, RTG_E_INVALID, "rtg_mesh_build: null argument");
+    *out = nullptr;
+    if (n_triangles > (1ull << 30)) return fail(ctx, RTG_E_LIMIT, "rtg_mesh_build: more than 2^30 triangles");
+    int rc = bind_device(ctx);
+    if (rc != RTG_OK) return rc;
+    const bool tris_on_device = is_device_pointer(triangles), normals_on_device = is_device_pointer(vertex_normals);
+    if (n_triangles < 2) {
+        // BvhTree::new() for no triangles, the triangle's own single-leaf tree for one (bvh_subdivide.rs:10-13):
+        // nothing to split, so the flattened tree is written here
+        rtg_tri tri{};
+        double normals[9];
+        rtg_bvh_node node{};
+        for (int k = 0; k < 3; k++) {
+            node.lo[k] = std::numeric_limits<double>::infinity();
+            node.hi[k] = -std::numeric_limits<double>::infinity();
+        }
+        if (n_triangles == 1) {
+            HIP_TRY(ctx, hipMemcpy(&tri, triangles, sizeof(tri), tris_on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+            if (vertex_normals)
+                HIP_TRY(ctx, hipMemcpy(normals, vertex_normals, sizeof(normals),
+                                       normals_on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+            for (int v = 0; v < 3; v++)
+                for (int k = 0; k < 3; k++) {
+                    double c = tri.p[v][k];
+                    if (!std::isfinite(c)) return fail(ctx, RTG_E_INVALID, "rtg_mesh_build: a triangle vertex is not finite");
+                    if (c < node.lo[k] || (c == node.lo[k] && std::signbit(c))) node.lo[k] = c;
+                    if (c > node.hi[k] || (c == node.hi[k] && !std::signbit(c))) node.hi[k] = c;
+                }
+            node.leaf_end = 1;
+        }
+        rtg_bvh bvh{};
+        bvh.nodes = &node;
+        bvh.n_nodes = 1;
+        bvh.leaves = &tri;
+        bvh.n_leaves = n_triangles;
+        bvh.vertex_normals = (n_triangles && vertex_normals) ? normals : nullptr;
+        bvh.root = 0;
+        return rtg_mesh_create(ctx, &bvh, out);
+    }
+
+    void *tmp_tris = nullptr, *tmp_normals = nullptr;
+    const rtg_tri *d_tris = triangles;
+    const double *d_normals = vertex_normals;
+    if (!tris_on_device) {
+        rc = upload(ctx, triangles, (size_t)n_triangles * sizeof(rtg_tri), &tmp_tris);
+        d_tris = (const rtg_tri *)tmp_tris;
+    }
+    if (rc == RTG_OK && vertex_normals && !normals_on_device) {
+        rc = upload(ctx, vertex_normals, (size_t)n_triangles * 72, &tmp_normals);
+        d_normals = (const double *)tmp_normals;
+    }
+    BuiltMesh built;
+    if (rc == RTG_OK) {
+        std::string err;
+        hipError_t e = build_subdivide_device(ctx->stream, d_tris, (uint32_t)n_triangles, d_normals, &built, err);
+        if (e != hipSuccess)
+            rc = fail(ctx, e == hipErrorInvalidValue ? RTG_E_INVALID : (e == hipErrorOutOfMemory ? RTG_E_NOMEM : RTG_E_HIP),
+                      "rtg_mesh_build: %s", err.c_str());
+    }
+    if (tmp_tris) (void)hipFree(tmp_tris);
+    if (tmp_normals) (void)hipFree(tmp_normals);
+    if (rc != RTG_OK) return rc;
+
+    rtg_mesh *m = new (std::nothrow) rtg_mesh();
+    if (!m) {
+        (void)hipFree(built.d_slab);
+        (void)hipFree(built.d_nodes);
+        (void)hipFree(built.d_leaf_source);
+        if (built.d_normals) (void)hipFree(built.d_normals);
+        return fail(ctx, RTG_E_NOMEM, "out of host memory");
+    }
+    m->ctx = ctx;
+    m->n_leaves = n_triangles;
+    m->d_slab = built.d_slab;
+    m->d_nodes = built.d_nodes;
+    m->d_normals = built.d_normals;
+    m->d_leaf_source = built.d_leaf_source;
+    std::memcpy(m->bounds, built.bounds, sizeof(m->bounds));
+    const size_t n = built.n_nodes;
+    m->dev.nodes = (const DevNode *)m->d_nodes;
+    m->dev.slab = (const uint8_t *)m->d_slab;
+    m->dev.tnodes = (const DevNode *)(m->dev.slab + sizeof(MeshSlabHeader) + n * sizeof(HotNode));
+    m->dev.tris = (const DevTri *)(m->dev.slab + sizeof(MeshSlabHeader) + n * (sizeof(HotNode) + sizeof(DevNode)));
+    m->dev.normals = (const double *)m->d_normals;
+    m->dev.n_nodes = built.n_nodes;
+    m->dev.root = built.root;
+    m->dev.depth = built.depth;
+    m->dev.fast_div_ok = built.fast_div_ok;
+    m->dev.f32_ok = built.f32_ok && std::isfinite(built.coord_max) ? 1u : 0u;
+    m->dev.coord_max = std::nextafter((float)built.coord_max, std::numeric_limits<float>::infinity());
+    *out = m;
+    return RTG_OK;
+}
+
+int rtg_mesh_sizes(const rtg_mesh *mesh, uint64_t *n_nodes, uint64_t *n_leaves, uint32_t *root, uint32_t *depth) {
+    if (!mesh) return fail(nullptr, RTG_E_INVALID, "null mesh");
+    if (n_nodes) *n_nodes = mesh->dev.n_nodes;
+    if (n_leaves) *n_leaves = mesh->n_leaves;
+    if (root) *root = mesh->dev.root;
+    if (depth) *depth = mesh->dev.depth;
+    return RTG_OK;
+}
+
+int rtg_mesh_read_bvh(const rtg_mesh *mesh, rtg_bvh_node *nodes, rtg_tri *leaves, uint32_t *leaf_source) {
+    if (!mesh || !mesh->ctx) return fail(nullptr, RTG_E_INVALID, "null mesh");
+    rtg_ctx *ctx = mesh->ctx;
+    int rc = bind_device(ctx);
+    if (rc != RTG_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t nn = mesh->dev.n_nodes, nl = (size_t)mesh->n_leaves;
+    const size_t chunk = 1u << 16;
+    if (nodes && nn) {
+        std::vector<DevNode> tmp(std::min(chunk, nn));
+        for (size_t at = 0; at < nn; at += chunk) {
+            size_t k = std::min(chunk, nn - at);
+            HIP_TRY(ctx, hipMemcpy(tmp.data(), mesh->dev.nodes + at, k * sizeof(DevNode), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < k; i++) {
+                rtg_bvh_node &d = nodes[at + i];
+                std::memcpy(d.lo, tmp[i].lo, 24);
+                std::memcpy(d.hi, tmp[i].hi, 24);
+                d.child_begin = tmp[i].link;
+                d.child_end = tmp[i].link + (tmp[i].nchild & 0x7FFFFFFFu);
+                d.leaf_begin = tmp[i].leaf_begin;
+                d.leaf_end = tmp[i].leaf_begin + tmp[i].leaf_count;
+            }
+        }
+    }
+    if (leaves && nl) {
+        std::vector<DevTri> tmp(std::min(chunk, nl));
+        for (size_t at = 0; at < nl; at += chunk) {
+            size_t k = std::min(chunk, nl - at);
+            HIP_TRY(ctx, hipMemcpy(tmp.data(), mesh->dev.tris + at, k * sizeof(DevTri), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < k; i++) std::memcpy(leaves[at + i].p, tmp[i].p, 72);
+        }
+    }
+    if (leaf_source && nl) {
+        if (mesh->d_leaf_source)
+            HIP_TRY(ctx, hipMemcpy(leaf_source, mesh->d_leaf_source, nl * 4, hipMemcpyDeviceToHost));
+        else
+            for (size_t i = 0; i < nl; i++) leaf_source[i] = (uint32_t)i;
+    }
     return RTG_OK;
 }
 

@@ -1,0 +1,500 @@
+// rtg_build.hip -- BvhForest::new(triangles).subdivide() followed by Bvh::new, on the device.
+//
+// The tree is the one the CPU builder makes, node for node and bit for bit
+// (tree/bvh.rs:48-58 one single-leaf tree per triangle with the triangle's box; tree/bvh_subdivide.rs:8-43 the
+// recursive median-position split; tree/bvh.rs:80-106 the flattening): what changes is the order of the work.
+// The recursion becomes a loop over tree levels in which every segment of the triangle permutation that still
+// holds two or more triangles is split at once:
+//
+//   * subdivide_once's stable sort of a segment by the box centre on the chosen axis is one device-wide stable
+//     radix sort per level, on the key (segment start, rank of the centre on the segment's axis).  Ranks come from
+//     three sorts of all centres made once up front; equal centres share a rank, so ties keep their previous order
+//     exactly as the stable comparison sort keeps them.
+//   * the union of a segment's boxes (bvh_subdivide.rs:22 and BvhTree::add_node, bvh.rs:72-75) is a min/max
+//     reduction, exact in any order: lanes reduce runs of one segment inside the wave and the run heads finish
+//     with 64-bit integer atomics on an order-preserving image of the doubles (-0.0 below +0.0, as IEEE
+//     minimum/maximum order them, geo/bounds.rs:28-33).
+//   * the binary search for the split coordinate follows the probe order of the standard library the reference
+//     used (first probed equal element wins), then the 1 % / 99 % clamp (bvh_subdivide.rs:29-38).
+//
+// Build nodes live in pre-order slots (a subtree over k triangles owns 2k-1 consecutive slots), which is also the
+// threaded layout the traversal kernels read; the position of a node's entry in the reference's flattened order
+// (children after all descendants, root last) follows from the same counts.  The last two kernels write the mesh
+// slab, the reference-order node array and the leaf -> source-triangle map.
+#include <hip/hip_runtime.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+
+#include <string>
+#include <vector>
+
+#include "rtg_launch.hpp"
+
+namespace rtg {
+namespace {
+
+struct BuildNode {
+    uint32_t begin, count;   // segment of the triangle permutation
+    uint32_t base;           // entries of the flattened array emitted before this subtree's descendants
+    uint32_t ref;            // index of this node's entry in the flattened array
+    uint32_t split;          // triangles in the left child (0 while unsplit / for a leaf)
+    uint32_t axis;           // bits 0..1 sort axis, bit 31 = last of its siblings
+};
+
+constexpr uint64_t kSign = 0x8000000000000000ull;
+__host__ __device__ inline uint64_t ord_of(double x) {
+    uint64_t u;
+    __builtin_memcpy(&u, &x, 8);
+    return (u & kSign) ? ~u : (u | kSign);
+}
+__host__ __device__ inline double ord_back(uint64_t k) {
+    uint64_t u = (k & kSign) ? (k ^ kSign) : ~k;
+    double x;
+    __builtin_memcpy(&x, &u, 8);
+    return x;
+}
+__device__ inline uint64_t shfl_down_u64(uint64_t v, int d) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_down(lo, d, 64);
+    hi = __shfl_down(hi, d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Triangle boxes (geo/triangle.rs:43-45), box centres (geo/bounds.rs:38-40) and the sort image of the centres
+// (-0.0 folded onto +0.0: the two compare equal in the reference's sort).  flags bit 0: a vertex is not finite.
+__global__ void k_prepare(const double *__restrict__ tris, uint32_t n, double *__restrict__ tb,
+                          double *__restrict__ centre, double *__restrict__ sort_key, uint32_t *__restrict__ iota,
+                          uint32_t *__restrict__ flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *p = tris + (size_t)i * 9;
+    bool finite = true;
+    for (int a = 0; a < 3; a++) {
+        double v0 = p[a], v1 = p[3 + a], v2 = p[6 + a];
+        finite = finite && (fabs(v0) < kInf) && (fabs(v1) < kInf) && (fabs(v2) < kInf);
+        uint64_t o0 = ord_of(v0), o1 = ord_of(v1), o2 = ord_of(v2);
+        uint64_t mn = o0 < o1 ? o0 : o1, mx = o0 > o1 ? o0 : o1;
+        mn = mn < o2 ? mn : o2;
+        mx = mx > o2 ? mx : o2;
+        double lo = ord_back(mn), hi = ord_back(mx);
+        tb[(size_t)i * 6 + a] = lo;
+        tb[(size_t)i * 6 + 3 + a] = hi;
+        double c = (lo + hi) / 2.0;
+        centre[(size_t)a * n + i] = c;
+        sort_key[(size_t)a * n + i] = c == 0.0 ? 0.0 : c;
+    }
+    iota[i] = i;
+    if (!finite) atomicOr(flags, 1u);
+}
+
+__global__ void k_run_heads(const double *__restrict__ sorted, uint32_t n, uint32_t *__restrict__ heads) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    heads[j] = (j == 0 || sorted[j] != sorted[j - 1]) ? j : 0u;
+}
+
+__global__ void k_scatter_rank(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ run_start, uint32_t n,
+                               uint32_t *__restrict__ rank) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    rank[perm[j]] = run_start[j];
+}
+
+__global__ void k_init(BuildNode *nodes, uint64_t *bounds, uint32_t n) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        nodes[0] = BuildNode{0u, n, 0u, 2u * n - 2u, 0u, 0x80000000u};
+        for (int k = 0; k < 3; k++) {
+            bounds[k] = ord_of(kInf);
+            bounds[3 + k] = ord_of(-kInf);
+        }
+    }
+}
+
+// Moves every triangle of a segment that was just split (or, with `initial`, every triangle into the root) to its
+// child segment and adds its box to the child's.
+__global__ void k_assign(const BuildNode *__restrict__ nodes, uint32_t *__restrict__ seg,
+                         const uint32_t *__restrict__ ids, const double *__restrict__ tb, uint32_t n, int initial,
+                         unsigned long long *__restrict__ bounds) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t child = 0xFFFFFFFFu;
+    uint64_t v[6];
+    for (int k = 0; k < 3; k++) {
+        v[k] = ~0ull;
+        v[3 + k] = 0ull;
+    }
+    if (i < n) {
+        if (initial) {
+            child = 0;
+        } else {
+            uint32_t x = seg[i];
+            BuildNode nd = nodes[x];
+            if (nd.count >= 2) {
+                child = (i - nd.begin < nd.split) ? x + 1 : x + 2 * nd.split;
+                seg[i] = child;
+            }
+        }
+        if (child != 0xFFFFFFFFu) {
+            const double *b = tb + (size_t)ids[i] * 6;
+            for (int k = 0; k < 6; k++) v[k] = ord_of(b[k]);
+        }
+    }
+    // runs of one child are contiguous: after the steps a run's first lane holds the run's union
+    const int lane = threadIdx.x & 63;
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t oc = __shfl_down(child, d, 64);
+        bool take = (lane + d < 64) && oc == child;
+        for (int k = 0; k < 3; k++) {
+            uint64_t olo = shfl_down_u64(v[k], d), ohi = shfl_down_u64(v[3 + k], d);
+            if (take) {
+                v[k] = olo < v[k] ? olo : v[k];
+                v[3 + k] = ohi > v[3 + k] ? ohi : v[3 + k];
+            }
+        }
+    }
+    uint32_t prev = __shfl_up(child, 1, 64);
+    bool head = (lane == 0) || prev != child;
+    if (head && child != 0xFFFFFFFFu) {
+        unsigned long long *b = bounds + (size_t)child * 6;
+        for (int k = 0; k < 3; k++) {
+            atomicMin(b + k, (unsigned long long)v[k]);
+            atomicMax(b + 3 + k, (unsigned long long)v[3 + k]);
+        }
+    }
+}
+
+// subdivide_once, first half (bvh_subdivide.rs:22-27): the sort axis (the last of the largest extents) and the
+// split coordinate of every active segment.
+__global__ void k_plan(BuildNode *__restrict__ nodes, const uint64_t *__restrict__ bounds,
+                       const uint32_t *__restrict__ active, uint32_t n_active, double *__restrict__ split_coord) {
+    uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_active) return;
+    uint32_t x = active[a];
+    double lo[3], dim[3];
+    for (int k = 0; k < 3; k++) {
+        lo[k] = ord_back(bounds[(size_t)x * 6 + k]);
+        dim[k] = ord_back(bounds[(size_t)x * 6 + 3 + k]) - lo[k];
+    }
+    int axis = 0;
+    for (int k = 1; k < 3; k++)
+        if (dim[k] >= dim[axis]) axis = k;
+    split_coord[a] = lo[axis] + dim[axis] / 2.0;
+    nodes[x].axis = (nodes[x].axis & 0x80000000u) | (uint32_t)axis;
+}
+
+__global__ void k_keys(const BuildNode *__restrict__ nodes, const uint32_t *__restrict__ seg,
+                       const uint32_t *__restrict__ ids, const uint32_t *__restrict__ rank, uint32_t n,
+                       uint32_t rank_bits, uint64_t *__restrict__ keys) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    BuildNode nd = nodes[seg[i]];
+    uint32_t r = nd.count >= 2 ? rank[(size_t)(nd.axis & 3u) * n + ids[i]] : 0u;
+    keys[i] = ((uint64_t)nd.begin << rank_bits) | r;
+}
+
+// subdivide_once, second half (bvh_subdivide.rs:29-42), and the two child nodes (bvh_subdivide.rs:16-19).
+__global__ void k_split(BuildNode *__restrict__ nodes, uint64_t *__restrict__ bounds,
+                        const uint32_t *__restrict__ active, uint32_t n_active, const double *__restrict__ split_coord,
+                        const uint32_t *__restrict__ ids, const double *__restrict__ centre, uint32_t n,
+                        uint32_t *__restrict__ next_active, uint32_t *__restrict__ next_count) {
+    uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_active) return;
+    const uint32_t x = active[a];
+    BuildNode nd = nodes[x];
+    const uint32_t b = nd.begin, k = nd.count;
+    const double *key = centre + (size_t)(nd.axis & 3u) * n;
+    const double want = split_coord[a];
+    uint32_t size = k, left = 0, right = k;
+    while (left < right) {
+        uint32_t mid = left + size / 2;
+        double v = key[ids[b + mid]];
+        if (v < want)
+            left = mid + 1;
+        else if (v > want)
+            right = mid;
+        else {
+            left = mid;
+            break;
+        }
+        size = right - left;
+    }
+    uint32_t split = left;
+    uint32_t min_split = (uint32_t)((double)k * 0.01);
+    if (min_split < 1) min_split = 1;
+    uint32_t max_split = k - min_split;
+    if (split < min_split) split = min_split;
+    if (split > max_split) split = max_split;
+    nodes[x].split = split;
+    const uint32_t l = x + 1, r = x + 2 * split;
+    nodes[l] = BuildNode{b, split, nd.base, nd.base + 2 * k - 4, 0u, 0u};
+    nodes[r] = BuildNode{b + split, k - split, nd.base + 2 * split - 2, nd.base + 2 * k - 3, 0u, 0x80000000u};
+    for (int c = 0; c < 3; c++) {
+        bounds[(size_t)l * 6 + c] = ord_of(kInf);
+        bounds[(size_t)l * 6 + 3 + c] = ord_of(-kInf);
+        bounds[(size_t)r * 6 + c] = ord_of(kInf);
+        bounds[(size_t)r * 6 + 3 + c] = ord_of(-kInf);
+    }
+    if (split >= 2) next_active[atomicAdd(next_count, 1u)] = l;
+    if (k - split >= 2) next_active[atomicAdd(next_count, 1u)] = r;
+}
+
+// Node outputs: the threaded node and its single-precision companion at the pre-order slot, the reference-order
+// node at the flattened index, and the coordinate-range summary the traversal kernels' fast paths depend on.
+// summary[0] bit 0: some coordinate outside the reciprocal window, bit 1: outside the single-precision window;
+// summary64: bits of the largest |coordinate|.
+__global__ void k_emit_nodes(const BuildNode *__restrict__ nodes, const uint64_t *__restrict__ bounds, uint32_t n_nodes,
+                             HotNode *__restrict__ hot, DevNode *__restrict__ thr, DevNode *__restrict__ ref,
+                             uint32_t *__restrict__ summary, unsigned long long *__restrict__ summary64) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bad = 0;
+    double cmax = 0.0;
+    if (s < n_nodes) {
+        BuildNode nd = nodes[s];
+        DevNode t;
+        for (int k = 0; k < 3; k++) {
+            t.lo[k] = ord_back(bounds[(size_t)s * 6 + k]);
+            t.hi[k] = ord_back(bounds[(size_t)s * 6 + 3 + k]);
+        }
+        const uint32_t k = nd.count;
+        t.link = s + 2 * k - 1;
+        t.nchild = 0;
+        t.leaf_begin = nd.begin;
+        t.leaf_count = k == 1 ? 1u : 0u;
+        thr[s] = t;
+        HotNode h;
+        for (int c = 0; c < 3; c++) {
+            h.planes[2 * c] = (float)t.lo[c];
+            h.planes[2 * c + 1] = (float)t.hi[c];
+            for (int e = 0; e < 2; e++) {
+                double v = e ? t.hi[c] : t.lo[c];
+                double m = fabs(v);
+                if (!(v == 0.0 || (m >= 0x1p-600 && m <= 0x1p400))) bad |= 1u;
+                if (!(v == 0.0 || (m >= 0x1p-40 && m <= 0x1p40))) bad |= 2u;
+                if (m > cmax) cmax = m;
+            }
+        }
+        h.skip = t.link;
+        h.leaf_ref = k == 1 ? nd.begin : 0xFFFFFFFFu;
+        hot[s] = h;
+        DevNode r = t;
+        r.link = k == 1 ? nd.base : nd.base + 2 * k - 4;
+        r.nchild = (k == 1 ? 0u : 2u) | (nd.axis & 0x80000000u);
+        ref[nd.ref] = r;
+    }
+    uint64_t m = ord_of(cmax);          // cmax >= 0: the order image is monotone
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t o = shfl_down_u64(m, d);
+        uint32_t ob = __shfl_down(bad, d, 64);
+        if ((int)(threadIdx.x & 63) + d < 64) {
+            m = o > m ? o : m;
+            bad |= ob;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad) atomicOr(summary, bad);
+        atomicMax(summary64, (unsigned long long)m);
+    }
+}
+
+// Leaves in traversal order (Bvh::add_bvh_tree pushes a tree's leaves before its children, bvh.rs:92-95): leaf p
+// is triangle ids[p].
+__global__ void k_emit_leaves(const double *__restrict__ tris, const double *__restrict__ normals_in,
+                              const uint32_t *__restrict__ ids, uint32_t n, DevTri *__restrict__ out,
+                              double *__restrict__ normals_out, uint32_t *__restrict__ leaf_source) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t id = ids[p];
+    DevTri t;
+    for (int k = 0; k < 9; k++) t.p[k] = tris[(size_t)id * 9 + k];
+    t.source = p;
+    t.pad = 0;
+    out[p] = t;
+    if (normals_in)
+        for (int k = 0; k < 9; k++) normals_out[(size_t)p * 9 + k] = normals_in[(size_t)id * 9 + k];
+    leaf_source[p] = id;
+}
+
+struct Buffers {
+    std::vector<void *> owned;
+    ~Buffers() {
+        for (void *p : owned)
+            if (p) (void)hipFree(p);
+    }
+    hipError_t get(size_t bytes, void **out) {
+        *out = nullptr;
+        hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+        if (e == hipSuccess) owned.push_back(*out);
+        return e;
+    }
+    void release(void *p) {           // ownership passes to the caller
+        for (void *&q : owned)
+            if (q == p) q = nullptr;
+    }
+};
+
+inline uint32_t grid_for(uint64_t n) { return (uint32_t)((n + 255) / 256); }
+
+} // namespace
+
+#define RTG_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) {                                                                                        \
+            (void)hipGetLastError();                                                                                   \
+            err = std::string(#expr) + ": " + hipGetErrorString(e_);                                                   \
+            return e_;                                                                                                 \
+        }                                                                                                              \
+    } while (0)
+
+hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uint32_t n, const double *d_normals_in,
+                                  BuiltMesh *out, std::string &err) {
+    *out = BuiltMesh{};
+    if (n < 2 || n > (1u << 30)) {
+        err = "build_subdivide_device: triangle count out of range";
+        return hipErrorInvalidValue;
+    }
+    const uint32_t n_nodes = 2 * n - 1;
+    uint32_t bits = 1;
+    while ((1ull << bits) < n) bits++;           // positions and ranks are below n
+    const double *tris = reinterpret_cast<const double *>(d_tris);
+
+    Buffers buf;
+    double *tb, *centre, *sort_key, *sorted_key, *split_coord;
+    uint32_t *iota, *perm, *heads, *run_start, *rank, *ids_a, *ids_b, *seg, *active_a, *active_b, *small;
+    uint64_t *keys_a, *keys_b, *bounds;
+    BuildNode *nodes;
+    RTG_TRY(buf.get((size_t)n * 48, (void **)&tb));
+    RTG_TRY(buf.get((size_t)n * 24, (void **)&centre));
+    RTG_TRY(buf.get((size_t)n * 24, (void **)&sort_key));
+    RTG_TRY(buf.get((size_t)n * 8, (void **)&sorted_key));
+    RTG_TRY(buf.get((size_t)n * 4, (void **)&iota));
+    RTG_TRY(buf.get((size_t)n * 4, (void **)&perm));
+    RTG_TRY(buf.get((size_t)n * 4, (void **)&heads));
+    RTG_TRY(buf.get((size_t)n * 4, (void **)&run_start));
+    RTG_TRY(buf.get((size_t)n * 12, (void **)&rank));
+    RTG_TRY(buf.get((size_t)n * 4, (void **)&ids_a));
+    RTG_TRY(buf.get((size_t)n * 4, (void **)&ids_b));
+    RTG_TRY(buf.get((size_t)n * 4, (void **)&seg));
+    RTG_TRY(buf.get((size_t)n * 8, (void **)&keys_a));
+    RTG_TRY(buf.get((size_t)n * 8, (void **)&keys_b));
+    RTG_TRY(buf.get(((size_t)n / 2 + 1) * 4, (void **)&active_a));
+    RTG_TRY(buf.get(((size_t)n / 2 + 1) * 4, (void **)&active_b));
+    RTG_TRY(buf.get(((size_t)n / 2 + 1) * 8, (void **)&split_coord));
+    RTG_TRY(buf.get((size_t)n_nodes * sizeof(BuildNode), (void **)&nodes));
+    RTG_TRY(buf.get((size_t)n_nodes * 48, (void **)&bounds));
+    RTG_TRY(buf.get(64, (void **)&small));       // [0] vertex flags, [1] next-active count, [2] range summary, [4..5] max |c|
+    RTG_TRY(hipMemsetAsync(small, 0, 64, stream));
+
+    size_t temp_rank = 0, temp_level = 0, temp_scan = 0;
+    RTG_TRY(rocprim::radix_sort_pairs(nullptr, temp_rank, sort_key, sorted_key, iota, perm, (size_t)n, 0u, 64u, stream));
+    RTG_TRY(rocprim::radix_sort_pairs(nullptr, temp_level, keys_a, keys_b, ids_a, ids_b, (size_t)n, 0u, 2 * bits, stream));
+    RTG_TRY(rocprim::inclusive_scan(nullptr, temp_scan, heads, run_start, (size_t)n, rocprim::maximum<uint32_t>(), stream));
+    size_t temp_bytes = temp_rank > temp_level ? temp_rank : temp_level;
+    if (temp_scan > temp_bytes) temp_bytes = temp_scan;
+    void *temp;
+    RTG_TRY(buf.get(temp_bytes, &temp));
+
+    const uint32_t g = grid_for(n);
+    hipLaunchKernelGGL(k_prepare, dim3(g), dim3(256), 0, stream, tris, n, tb, centre, sort_key, iota, small);
+    RTG_TRY(hipGetLastError());
+    for (int a = 0; a < 3; a++) {
+        size_t tbytes = temp_bytes;
+        RTG_TRY(rocprim::radix_sort_pairs(temp, tbytes, sort_key + (size_t)a * n, sorted_key, iota, perm, (size_t)n, 0u,
+                                          64u, stream));
+        hipLaunchKernelGGL(k_run_heads, dim3(g), dim3(256), 0, stream, sorted_key, n, heads);
+        RTG_TRY(hipGetLastError());
+        tbytes = temp_bytes;
+        RTG_TRY(rocprim::inclusive_scan(temp, tbytes, heads, run_start, (size_t)n, rocprim::maximum<uint32_t>(), stream));
+        hipLaunchKernelGGL(k_scatter_rank, dim3(g), dim3(256), 0, stream, perm, run_start, n, rank + (size_t)a * n);
+        RTG_TRY(hipGetLastError());
+    }
+    uint32_t h_small[16];
+    RTG_TRY(hipMemcpyAsync(h_small, small, 64, hipMemcpyDeviceToHost, stream));
+    RTG_TRY(hipStreamSynchronize(stream));
+    if (h_small[0] & 1u) {
+        err = "a triangle vertex is not finite";
+        return hipErrorInvalidValue;
+    }
+
+    RTG_TRY(hipMemcpyAsync(ids_a, iota, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+    RTG_TRY(hipMemsetAsync(seg, 0, (size_t)n * 4, stream));
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, stream, nodes, bounds, n);
+    RTG_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_assign, dim3(g), dim3(256), 0, stream, nodes, seg, ids_a, tb, n, 1,
+                       (unsigned long long *)bounds);
+    RTG_TRY(hipGetLastError());
+    RTG_TRY(hipMemsetAsync(active_a, 0, 4, stream));     // the root is the only active segment
+    uint32_t n_active = 1, depth = 1;
+    uint32_t *ids_cur = ids_a, *ids_next = ids_b;
+    while (n_active) {
+        const uint32_t ga = grid_for(n_active);
+        hipLaunchKernelGGL(k_plan, dim3(ga), dim3(256), 0, stream, nodes, bounds, active_a, n_active, split_coord);
+        RTG_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_keys, dim3(g), dim3(256), 0, stream, nodes, seg, ids_cur, rank, n, bits, keys_a);
+        RTG_TRY(hipGetLastError());
+        size_t tbytes = temp_bytes;
+        RTG_TRY(rocprim::radix_sort_pairs(temp, tbytes, keys_a, keys_b, ids_cur, ids_next, (size_t)n, 0u, 2 * bits, stream));
+        RTG_TRY(hipMemsetAsync(small + 1, 0, 4, stream));
+        hipLaunchKernelGGL(k_split, dim3(ga), dim3(256), 0, stream, nodes, bounds, active_a, n_active, split_coord,
+                           ids_next, centre, n, active_b, small + 1);
+        RTG_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_assign, dim3(g), dim3(256), 0, stream, nodes, seg, ids_next, tb, n, 0,
+                           (unsigned long long *)bounds);
+        RTG_TRY(hipGetLastError());
+        RTG_TRY(hipMemcpyAsync(&n_active, small + 1, 4, hipMemcpyDeviceToHost, stream));
+        RTG_TRY(hipStreamSynchronize(stream));
+        if (n_active > n / 2) {
+            err = "build_subdivide_device: active segment count out of range";
+            return hipErrorUnknown;
+        }
+        std::swap(ids_cur, ids_next);
+        std::swap(active_a, active_b);
+        depth++;
+    }
+
+    // outputs
+    const size_t off_hot = sizeof(MeshSlabHeader), off_tnodes = off_hot + (size_t)n_nodes * sizeof(HotNode),
+                 off_tris = off_tnodes + (size_t)n_nodes * sizeof(DevNode), slab_bytes = off_tris + (size_t)n * sizeof(DevTri);
+    uint8_t *slab;
+    DevNode *ref;
+    uint32_t *leaf_source;
+    double *normals_out = nullptr;
+    RTG_TRY(buf.get(slab_bytes, (void **)&slab));
+    RTG_TRY(buf.get((size_t)n_nodes * sizeof(DevNode), (void **)&ref));
+    RTG_TRY(buf.get((size_t)n * 4, (void **)&leaf_source));
+    if (d_normals_in) RTG_TRY(buf.get((size_t)n * 72, (void **)&normals_out));
+    RTG_TRY(hipMemsetAsync(slab, 0, sizeof(MeshSlabHeader), stream));
+    hipLaunchKernelGGL(k_emit_nodes, dim3(grid_for(n_nodes)), dim3(256), 0, stream, nodes, bounds, n_nodes,
+                       (HotNode *)(slab + off_hot), (DevNode *)(slab + off_tnodes), ref, small + 2,
+                       (unsigned long long *)(small + 4));
+    RTG_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_emit_leaves, dim3(g), dim3(256), 0, stream, tris, d_normals_in, ids_cur, n,
+                       (DevTri *)(slab + off_tris), normals_out, leaf_source);
+    RTG_TRY(hipGetLastError());
+    uint64_t root_bounds[6];
+    RTG_TRY(hipMemcpyAsync(h_small, small, 64, hipMemcpyDeviceToHost, stream));
+    RTG_TRY(hipMemcpyAsync(root_bounds, bounds, 48, hipMemcpyDeviceToHost, stream));
+    RTG_TRY(hipStreamSynchronize(stream));
+
+    out->d_slab = slab;
+    out->d_nodes = ref;
+    out->d_leaf_source = leaf_source;
+    out->d_normals = normals_out;
+    buf.release(slab);
+    buf.release(ref);
+    buf.release(leaf_source);
+    buf.release(normals_out);
+    out->n_nodes = n_nodes;
+    out->root = n_nodes - 1;
+    out->depth = depth;
+    out->fast_div_ok = (h_small[2] & 1u) ? 0u : 1u;
+    out->f32_ok = (h_small[2] & 2u) ? 0u : 1u;
+    uint64_t cm;
+    __builtin_memcpy(&cm, h_small + 4, 8);
+    out->coord_max = ord_back(cm);
+    for (int k = 0; k < 6; k++) out->bounds[k] = ord_back(root_bounds[k]);
+    return hipSuccess;
+}
+
+} // namespace rtg

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string>
+
 #include "rtg_device.hpp"
 
 namespace rtg {
@@ -72,6 +74,20 @@ hipError_t launch_spec_store(hipStream_t stream, const SpecMeta *meta, const rtg
                              uint64_t n, uint32_t slots_per_group, double *slots);
 hipError_t launch_spec_sum(hipStream_t stream, const uint32_t *groups, uint32_t n_groups, uint32_t slots_per_group,
                            const double *slots, double *frame_rgb, double *out_rgb, uint8_t *out_rgba8);
+
+// BvhForest::new(triangles).subdivide() + Bvh::new on the device (rtg_build.hip), for 2 <= n <= 2^30 triangles
+// already in device memory.  On success the four device allocations belong to the caller (hipFree).
+struct BuiltMesh {
+    void *d_slab = nullptr;          // MeshSlabHeader (zeroed) + hot nodes + threaded nodes + triangles
+    void *d_nodes = nullptr;         // reference-order DevNode x n_nodes
+    void *d_leaf_source = nullptr;   // u32 x n: the caller's triangle index of every leaf
+    void *d_normals = nullptr;       // 9 doubles per leaf in leaf order, or nullptr
+    uint32_t n_nodes = 0, root = 0, depth = 0, fast_div_ok = 0, f32_ok = 0;
+    double coord_max = 0.0;
+    double bounds[6] = {0, 0, 0, 0, 0, 0};
+};
+hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uint32_t n, const double *d_normals_in,
+                                  BuiltMesh *out, std::string &err);
 
 hipError_t launch_selftest_div(hipStream_t stream, uint64_t seed, uint32_t blocks, uint32_t per_thread, uint32_t family,
                                uint64_t *out3);

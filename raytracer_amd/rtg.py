@@ -115,6 +115,10 @@ _sig(lib.rtg_transform_from_forward, C.c_int, C.POINTER(C.c_double), C.POINTER(T
 _sig(lib.rtg_mesh_create, C.c_int, _vp, C.POINTER(Bvh), C.POINTER(_vp))
 _sig(lib.rtg_mesh_create_patches, C.c_int, _vp, C.POINTER(Bvh), C.POINTER(PatchSet), C.POINTER(_vp))
 _sig(lib.rtg_mesh_destroy, None, _vp)
+_sig(lib.rtg_mesh_build, C.c_int, _vp, _vp, C.c_uint64, _vp, C.POINTER(_vp))
+_sig(lib.rtg_mesh_sizes, C.c_int, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+     C.POINTER(C.c_uint32))
+_sig(lib.rtg_mesh_read_bvh, C.c_int, _vp, _vp, _vp, _vp)
 _sig(lib.rtg_mesh_bounds, C.c_int, _vp, C.POINTER(C.c_double))
 _sig(lib.rtg_scene_create, C.c_int, _vp, C.POINTER(SceneDesc), C.POINTER(_vp))
 _sig(lib.rtg_scene_destroy, None, _vp)
@@ -401,6 +405,11 @@ class Context:
     def mesh(self, bvh):
         return Mesh(self, bvh)
 
+    def build_mesh(self, tris, vertex_normals=None):
+        """BvhForest::new(tris).subdivide() + Bvh::new on the GPU; `tris` / `vertex_normals` are numpy arrays or
+        device addresses (then `tris` is (address, count))."""
+        return Mesh.build(self, tris, vertex_normals)
+
     def scene(self, objects):
         return Scene(self, objects)
 
@@ -431,6 +440,24 @@ class Mesh:
         self._h = h
         self.ctx = ctx
 
+    @classmethod
+    def build(cls, ctx, tris, vertex_normals=None):
+        self = cls.__new__(cls)
+        if isinstance(tris, tuple):
+            addr, n = tris
+            keep = None
+        else:
+            tris = np.ascontiguousarray(tris, dtype=np.float64).reshape(-1, 3, 3)
+            addr, n, keep = tris, tris.shape[0], tris
+        if isinstance(vertex_normals, np.ndarray):
+            vertex_normals = np.ascontiguousarray(vertex_normals, dtype=np.float64)
+        h = _vp()
+        ctx._check(lib.rtg_mesh_build(ctx._h, _ptr(addr), n, _ptr(vertex_normals), C.byref(h)))
+        self._keep = keep
+        self._h = h
+        self.ctx = ctx
+        return self
+
     @property
     def handle(self):
         return self._h.value
@@ -439,6 +466,21 @@ class Mesh:
         out = (C.c_double * 6)()
         self.ctx._check(lib.rtg_mesh_bounds(self._h, out))
         return np.array(list(out))
+
+    def sizes(self):
+        """(n_nodes, n_leaves, root, depth) of the flattened tree."""
+        nn, nl, root, depth = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        self.ctx._check(lib.rtg_mesh_sizes(self._h, C.byref(nn), C.byref(nl), C.byref(root), C.byref(depth)))
+        return nn.value, nl.value, root.value, depth.value
+
+    def read_bvh(self):
+        """(nodes NODE_DTYPE, leaves (n,3,3), leaf_source u32) copied back from the device."""
+        nn, nl, _, _ = self.sizes()
+        nodes = np.zeros(nn, dtype=NODE_DTYPE)
+        leaves = np.zeros((nl, 3, 3))
+        source = np.zeros(nl, dtype=np.uint32)
+        self.ctx._check(lib.rtg_mesh_read_bvh(self._h, _ptr(nodes), _ptr(leaves), _ptr(source)))
+        return nodes, leaves, source
 
     def close(self):
         if self._h:

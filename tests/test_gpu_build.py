@@ -1,0 +1,143 @@
+"""The tree built on the GPU (rtg_mesh_build) is the tree BvhForest::subdivide + Bvh::new make on the host
+(tree/bvh_subdivide.rs:8-43, tree/bvh.rs:80-106): node arrays, leaf order and leaf -> triangle map compared byte for
+byte with the host builder, on meshes chosen to hit the tie rules (equal centres, equal extents, probes landing on
+the split coordinate, the 1 % clamp, signed zeros)."""
+import time
+
+import numpy as np
+import pytest
+
+import scenes
+from raytracer_amd import rtg
+
+pytestmark = pytest.mark.gpu
+
+
+def _lattice(nx, ny):
+    """Axis-aligned flat quads on the integer lattice: every centre and every extent ties with many others."""
+    tris = []
+    for y in range(ny):
+        for x in range(nx):
+            a, b, c, d = (x, y, 0.0), (x + 1.0, y, 0.0), (x + 1.0, y + 1.0, 0.0), (x, y + 1.0, 0.0)
+            tris.append((a, b, c))
+            tris.append((a, c, d))
+    return np.array(tris, dtype=np.float64)
+
+
+def _soup(n, seed, quantum):
+    rng = np.random.default_rng(seed)
+    base = rng.uniform(-4.0, 4.0, size=(n, 1, 3))
+    tris = base + rng.uniform(-0.5, 0.5, size=(n, 3, 3))
+    if quantum:
+        tris = np.round(tris / quantum) * quantum
+    return np.ascontiguousarray(tris)
+
+
+def _cases():
+    yield "terrain", scenes.terrain(60, 40, seed=3)[0]
+    yield "lattice", _lattice(37, 23)
+    yield "lattice_cube", np.concatenate([_lattice(16, 16), _lattice(16, 16)[:, :, [2, 0, 1]], _lattice(16, 16)[:, :, [1, 2, 0]]])
+    yield "duplicates", np.repeat(_soup(1, 1, 0.0), 257, axis=0)
+    yield "soup", _soup(5000, 2, 0.0)
+    yield "soup_quantised", _soup(5000, 3, 0.25)
+    z = _soup(700, 4, 0.5)
+    z[z == 0.0] = -0.0                                     # negative zeros next to positive ones
+    z[::3][z[::3] == 0.0] = 0.0
+    yield "signed_zeros", z
+    skew = _soup(3000, 5, 0.0)
+    skew[:2900] *= 1e-3                                    # almost everything in one corner: the 1 % clamp decides
+    yield "skewed", skew
+    for n in (2, 3, 4, 5, 64, 65):
+        yield f"n{n}", _soup(n, 10 + n, 0.0)
+
+
+@pytest.mark.parametrize("name,tris", list(_cases()), ids=[c[0] for c in _cases()])
+def test_device_built_tree_equals_host_built_tree(gpu_ctx, name, tris):
+    normals = scenes.vertex_normals_for(tris) if name in ("terrain", "soup") else None
+    host = rtg.HostBvh(tris, normals)
+    mesh = gpu_ctx.build_mesh(tris, normals)
+    n_nodes, n_leaves, root, depth = mesh.sizes()
+    assert (n_nodes, n_leaves, root, depth) == (host.n_nodes, host.n_leaves, host.root, host.depth)
+    nodes, leaves, source = mesh.read_bvh()
+    assert np.array_equal(source, host.leaf_source())
+    assert leaves.tobytes() == host.leaves().tobytes()
+    assert nodes.tobytes() == host.nodes().tobytes()
+    assert mesh.bounds().tobytes() == host.bounds().tobytes()
+
+    # the device-written kernel layouts (threaded nodes, single-precision companions, triangles, normals) give the
+    # hits and points of the host-flattened mesh, in every traversal
+    reference = gpu_ctx.mesh(host)
+    lo, hi = host.bounds()[:3], host.bounds()[3:]
+    view = rtg.make_view(orig=(float((lo[0] + hi[0]) / 2), float((lo[1] + hi[1]) / 2), float(hi[2] + (hi - lo).max())))
+    rays = rtg.bench_mesh_rays(np.concatenate([lo - 0.1, hi + 0.1]), 4096, seed=7)
+    for traversal in (0, 1, 2):
+        gpu_ctx.set_option("traversal", traversal)
+        out = []
+        for m in (mesh, reference):
+            sc = gpu_ctx.scene([rtg.mesh_object(m, rtg.material((0.5, 0.5, 0.5)))])
+            h1, p1, _ = sc.render_primary(view, 96, 64, points=True)
+            h2, p2, _ = sc.trace(rays, points=True)
+            out.append((h1, p1, h2, p2))
+            sc.close()
+        for a, b in zip(*out):
+            assert a.tobytes() == b.tobytes()
+        assert (out[0][0]["leaf"] != 0xFFFFFFFF).any() or name.startswith("lattice") or name.startswith("n")
+    gpu_ctx.set_option("traversal", 2)
+    mesh.close()
+    reference.close()
+
+
+def test_trivial_and_invalid_inputs(gpu_ctx):
+    empty = gpu_ctx.build_mesh(np.zeros((0, 3, 3)))
+    host = rtg.HostBvh(np.zeros((0, 3, 3)))
+    assert empty.sizes()[:3] == (host.n_nodes, 0, host.root)
+    assert empty.read_bvh()[0].tobytes() == host.nodes().tobytes()
+    one = _soup(1, 9, 0.0)
+    one[0, 1, 2] = -0.0
+    single = gpu_ctx.build_mesh(one, scenes.vertex_normals_for(_soup(1, 9, 0.0)))
+    host = rtg.HostBvh(one)
+    nodes, leaves, source = single.read_bvh()
+    assert nodes.tobytes() == host.nodes().tobytes() and leaves.tobytes() == host.leaves().tobytes()
+    assert list(source) == [0]
+    for bad in (np.nan, np.inf, -np.inf):
+        tris = _soup(100, 1, 0.0)
+        tris[57, 2, 1] = bad
+        with pytest.raises(rtg.RtgError, match="not finite"):
+            gpu_ctx.build_mesh(tris)
+        with pytest.raises(rtg.RtgError, match="not finite"):
+            gpu_ctx.build_mesh(tris[57:58])
+
+
+def test_triangles_already_on_the_device(gpu_ctx):
+    import torch
+    tris = scenes.terrain(50, 30, seed=5)[0]
+    normals = scenes.vertex_normals_for(tris)
+    d_tris = torch.from_numpy(tris).cuda()
+    d_normals = torch.from_numpy(normals).cuda()
+    torch.cuda.synchronize()
+    mesh = gpu_ctx.build_mesh((d_tris.data_ptr(), tris.shape[0]), d_normals.data_ptr())
+    host = rtg.HostBvh(tris, normals)
+    nodes, leaves, source = mesh.read_bvh()
+    assert nodes.tobytes() == host.nodes().tobytes()
+    assert leaves.tobytes() == host.leaves().tobytes()
+    assert np.array_equal(source, host.leaf_source())
+
+
+def test_million_triangle_build(gpu_ctx):
+    import bench
+    tris = rtg.heightfield(*bench.GRID, bench.SEED, bench.LOCAL_SCALE)
+    t0 = time.perf_counter()
+    host = rtg.HostBvh(tris)
+    t1 = time.perf_counter()
+    gpu_ctx.build_mesh(tris[:1000]).close()               # first-use costs out of the timing
+    gpu_ctx.synchronize()
+    t2 = time.perf_counter()
+    mesh = gpu_ctx.build_mesh(tris)
+    gpu_ctx.synchronize()
+    t3 = time.perf_counter()
+    print(f"\n1M triangles: host build {t1 - t0:.2f} s, device build (upload included) {t3 - t2:.3f} s")
+    nodes, leaves, source = mesh.read_bvh()
+    assert np.array_equal(source, host.leaf_source())
+    assert nodes.tobytes() == host.nodes().tobytes()
+    assert leaves.tobytes() == host.leaves().tobytes()
+    assert mesh.sizes() == (host.n_nodes, host.n_leaves, host.root, host.depth)
