@@ -113,38 +113,81 @@ __global__ void k_init(BuildNode *nodes, uint64_t *bounds, uint32_t n) {
 }
 
 // Moves every triangle of a segment that was just split (or, with `initial`, every triangle into the root) to its
-// child segment and adds its box to the child's.
-__global__ void k_assign(const BuildNode *__restrict__ nodes, uint32_t *__restrict__ seg,
-                         const uint32_t *__restrict__ ids, const double *__restrict__ tb, uint32_t n, int initial,
-                         unsigned long long *__restrict__ bounds) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t child = 0xFFFFFFFFu;
+// child segment and adds its box to the child's.  A lane walks kAssignPerLane consecutive triangles: a child
+// segment that begins inside the lane's stretch ends there too or runs on into the next lanes; in the first case
+// the lane is the only writer of that child's box and stores it, otherwise the partial boxes are combined across
+// the wave (a child's lanes are neighbours) and across the block's four waves before the integer atomics, so the
+// few huge segments of the first levels cost a handful of atomics per block instead of one per wave.
+constexpr int kAssignPerLane = 16;
+constexpr uint32_t kNoChild = 0xFFFFFFFFu;
+__global__ __launch_bounds__(256) void k_assign(const BuildNode *__restrict__ nodes, uint32_t *__restrict__ seg,
+                                                const uint32_t *__restrict__ ids, const double *__restrict__ tb,
+                                                uint32_t n, int initial, unsigned long long *__restrict__ bounds) {
+    __shared__ uint32_t s_child[4];
+    __shared__ uint64_t s_v[4][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t first = (((uint64_t)blockIdx.x * 4 + wave) * 64 + lane) * kAssignPerLane;
+    uint32_t cur = kNoChild, cur_begin = 0, parent = kNoChild;
+    BuildNode nd{};
     uint64_t v[6];
-    for (int k = 0; k < 3; k++) {
-        v[k] = ~0ull;
-        v[3 + k] = 0ull;
-    }
-    if (i < n) {
+    auto reset = [&]() {
+        for (int k = 0; k < 3; k++) {
+            v[k] = ~0ull;
+            v[3 + k] = 0ull;
+        }
+    };
+    auto flush_atomic = [&](uint32_t child, const uint64_t *w) {
+        unsigned long long *b = bounds + (size_t)child * 6;
+        for (int k = 0; k < 3; k++) {
+            atomicMin(b + k, (unsigned long long)w[k]);
+            atomicMax(b + 3 + k, (unsigned long long)w[3 + k]);
+        }
+    };
+    reset();
+    for (int e = 0; e < kAssignPerLane; e++) {
+        const uint64_t i = first + e;
+        if (i >= n) break;
+        uint32_t child = kNoChild, child_begin = 0;
         if (initial) {
             child = 0;
         } else {
             uint32_t x = seg[i];
-            BuildNode nd = nodes[x];
+            if (x != parent) {
+                parent = x;
+                nd = nodes[x];
+            }
             if (nd.count >= 2) {
-                child = (i - nd.begin < nd.split) ? x + 1 : x + 2 * nd.split;
+                bool left = (uint32_t)i - nd.begin < nd.split;
+                child = left ? x + 1 : x + 2 * nd.split;
+                child_begin = left ? nd.begin : nd.begin + nd.split;
                 seg[i] = child;
             }
         }
-        if (child != 0xFFFFFFFFu) {
+        if (child != cur) {
+            if (cur != kNoChild) {
+                if (cur_begin >= first && !initial) {        // the whole child segment was walked by this lane
+                    for (int k = 0; k < 6; k++) bounds[(size_t)cur * 6 + k] = v[k];
+                } else {
+                    flush_atomic(cur, v);
+                }
+            }
+            cur = child;
+            cur_begin = child_begin;
+            reset();
+        }
+        if (child != kNoChild) {
             const double *b = tb + (size_t)ids[i] * 6;
-            for (int k = 0; k < 6; k++) v[k] = ord_of(b[k]);
+            for (int k = 0; k < 3; k++) {
+                uint64_t lo = ord_of(b[k]), hi = ord_of(b[3 + k]);
+                v[k] = lo < v[k] ? lo : v[k];
+                v[3 + k] = hi > v[3 + k] ? hi : v[3 + k];
+            }
         }
     }
-    // runs of one child are contiguous: after the steps a run's first lane holds the run's union
-    const int lane = threadIdx.x & 63;
+    // the lanes whose last child is the same are neighbours: after the steps the first of them holds their union
     for (int d = 1; d < 64; d <<= 1) {
-        uint32_t oc = __shfl_down(child, d, 64);
-        bool take = (lane + d < 64) && oc == child;
+        uint32_t oc = __shfl_down(cur, d, 64);
+        bool take = (lane + d < 64) && oc == cur;
         for (int k = 0; k < 3; k++) {
             uint64_t olo = shfl_down_u64(v[k], d), ohi = shfl_down_u64(v[3 + k], d);
             if (take) {
@@ -153,14 +196,36 @@ __global__ void k_assign(const BuildNode *__restrict__ nodes, uint32_t *__restri
             }
         }
     }
-    uint32_t prev = __shfl_up(child, 1, 64);
-    bool head = (lane == 0) || prev != child;
-    if (head && child != 0xFFFFFFFFu) {
-        unsigned long long *b = bounds + (size_t)child * 6;
-        for (int k = 0; k < 3; k++) {
-            atomicMin(b + k, (unsigned long long)v[k]);
-            atomicMax(b + 3 + k, (unsigned long long)v[3 + k]);
+    uint32_t prev = __shfl_up(cur, 1, 64);
+    const bool head = (lane == 0) || prev != cur;
+    const uint32_t cur0 = __shfl(cur, 0, 64);
+    const bool uniform = __all(cur == cur0) != 0;
+    if (uniform) {
+        if (lane == 0) {
+            s_child[wave] = cur;
+            for (int k = 0; k < 6; k++) s_v[wave][k] = v[k];
         }
+    } else {
+        if (lane == 0) s_child[wave] = kNoChild;
+        if (head && cur != kNoChild) flush_atomic(cur, v);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = kNoChild;
+        uint64_t w[6];
+        for (int q = 0; q < 4; q++) {
+            if (s_child[q] != c) {
+                if (c != kNoChild) flush_atomic(c, w);
+                c = s_child[q];
+                for (int k = 0; k < 6; k++) w[k] = s_v[q][k];
+            } else if (c != kNoChild) {
+                for (int k = 0; k < 3; k++) {
+                    w[k] = s_v[q][k] < w[k] ? s_v[q][k] : w[k];
+                    w[3 + k] = s_v[q][3 + k] > w[3 + k] ? s_v[q][3 + k] : w[3 + k];
+                }
+            }
+        }
+        if (c != kNoChild) flush_atomic(c, w);
     }
 }
 
@@ -421,7 +486,8 @@ hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uin
     RTG_TRY(hipMemsetAsync(seg, 0, (size_t)n * 4, stream));
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, stream, nodes, bounds, n);
     RTG_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_assign, dim3(g), dim3(256), 0, stream, nodes, seg, ids_a, tb, n, 1,
+    const uint32_t g_assign = (uint32_t)(((uint64_t)n + 256 * kAssignPerLane - 1) / (256 * kAssignPerLane));
+    hipLaunchKernelGGL(k_assign, dim3(g_assign), dim3(256), 0, stream, nodes, seg, ids_a, tb, n, 1,
                        (unsigned long long *)bounds);
     RTG_TRY(hipGetLastError());
     RTG_TRY(hipMemsetAsync(active_a, 0, 4, stream));     // the root is the only active segment
@@ -439,7 +505,7 @@ hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uin
         hipLaunchKernelGGL(k_split, dim3(ga), dim3(256), 0, stream, nodes, bounds, active_a, n_active, split_coord,
                            ids_next, centre, n, active_b, small + 1);
         RTG_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_assign, dim3(g), dim3(256), 0, stream, nodes, seg, ids_next, tb, n, 0,
+        hipLaunchKernelGGL(k_assign, dim3(g_assign), dim3(256), 0, stream, nodes, seg, ids_next, tb, n, 0,
                            (unsigned long long *)bounds);
         RTG_TRY(hipGetLastError());
         RTG_TRY(hipMemcpyAsync(&n_active, small + 1, 4, hipMemcpyDeviceToHost, stream));
