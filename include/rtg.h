@@ -252,6 +252,10 @@ int rtg_mesh_create_patches(rtg_ctx *ctx, const rtg_bvh *bvh, const rtg_patch_se
  * reference panics on a NaN sort key, bvh_subdivide.rs:28): RTG_E_INVALID otherwise. */
 int rtg_mesh_build(rtg_ctx *ctx, const rtg_tri *triangles, uint64_t n_triangles, const double *vertex_normals,
                    rtg_mesh **out);
+/* rtg_mesh_build for a patch set: `facets` are the flat facets in any order and `patches->leaf_info[i]` describes
+ * facet i; the records follow their facets into leaf order. */
+int rtg_mesh_build_patches(rtg_ctx *ctx, const rtg_tri *facets, uint64_t n_facets, const rtg_patch_set *patches,
+                           rtg_mesh **out);
 /* Node and leaf counts, root index (`Bvh::root`) and depth of a mesh's flattened tree; any pointer may be NULL. */
 int rtg_mesh_sizes(const rtg_mesh *mesh, uint64_t *n_nodes, uint64_t *n_leaves, uint32_t *root, uint32_t *depth);
 /* Copies a mesh's flattened tree back to host arrays sized by rtg_mesh_sizes: `nodes` in the order of

@@ -722,6 +722,65 @@ int rtg_mesh_build(rtg_ctx *ctx, const rtg_tri *triangles, uint64_t n_triangles,
     return RTG_OK;
 }
 
+int rtg_mesh_build_patches(rtg_ctx *ctx, const rtg_tri *facets, uint64_t n_facets, const rtg_patch_set *ps,
+                           rtg_mesh **out) {
+    if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
+    if (!facets || !ps || !out) return fail(ctx, RTG_E_INVALID, "rtg_mesh_build_patches: null argument");
+    *out = nullptr;
+    if (ps->n_patches == 0 || !ps->patches) return fail(ctx, RTG_E_INVALID, "rtg_mesh_build_patches: no patches");
+    if (n_facets && !ps->leaf_info) return fail(ctx, RTG_E_INVALID, "rtg_mesh_build_patches: leaf_info is null");
+    if (ps->n_patches >= 0x7FFFFFFFull) return fail(ctx, RTG_E_LIMIT, "rtg_mesh_build_patches: too many patches");
+    if (ps->newton_steps > 64) return fail(ctx, RTG_E_LIMIT, "rtg_mesh_build_patches: newton_steps exceeds 64");
+    for (uint64_t i = 0; i < n_facets; i++)
+        if (ps->leaf_info[i].patch >= ps->n_patches)
+            return fail(ctx, RTG_E_INVALID, "rtg_mesh_build_patches: facet %llu names patch %u of %llu",
+                        (unsigned long long)i, ps->leaf_info[i].patch, (unsigned long long)ps->n_patches);
+    rtg_mesh *m = nullptr;
+    int rc = rtg_mesh_build(ctx, facets, n_facets, nullptr, &m);
+    if (rc != RTG_OK) return rc;
+    void *by_facet = nullptr;
+    rc = upload(ctx, ps->patches, (size_t)ps->n_patches * sizeof(rtg_trispline), &m->d_patches);
+    if (rc == RTG_OK) rc = upload(ctx, ps->leaf_info, (size_t)n_facets * sizeof(rtg_patch_leaf), &by_facet);
+    if (rc == RTG_OK && m->d_leaf_source) {              // built on the device: records go from facet to leaf order
+        hipError_t e = hipMalloc(&m->d_leaf_info, (size_t)n_facets * sizeof(rtg_patch_leaf));
+        if (e == hipSuccess)
+            e = launch_gather_leaf_info(ctx->stream, (const rtg_patch_leaf *)by_facet, (const uint32_t *)m->d_leaf_source,
+                                        (uint32_t)n_facets, (rtg_patch_leaf *)m->d_leaf_info);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            rc = fail(ctx, RTG_E_HIP, "rtg_mesh_build_patches: %s", hipGetErrorString(e));
+        }
+        (void)hipFree(by_facet);
+        by_facet = nullptr;
+    } else if (rc == RTG_OK) {
+        m->d_leaf_info = by_facet;                        // fewer than two facets: leaf order is facet order
+        by_facet = nullptr;
+    }
+    if (by_facet) (void)hipFree(by_facet);
+    MeshSlabHeader header{};
+    header.patches = (const rtg_trispline *)m->d_patches;
+    header.leaf_info = (const rtg_patch_leaf *)m->d_leaf_info;
+    header.newton_steps = ps->newton_steps;
+    if (rc == RTG_OK) {
+        hipError_t he = hipMemcpy(m->d_slab, &header, sizeof(header), hipMemcpyHostToDevice);
+        if (he != hipSuccess) {
+            (void)hipGetLastError();
+            rc = fail(ctx, RTG_E_HIP, "hipMemcpy of the patch header: %s", hipGetErrorString(he));
+        }
+    }
+    if (rc != RTG_OK) {
+        rtg_mesh_destroy(m);
+        return rc;
+    }
+    m->is_patches = true;
+    m->dev.patches = header.patches;
+    m->dev.leaf_info = header.leaf_info;
+    m->dev.newton_steps = ps->newton_steps;
+    *out = m;
+    return RTG_OK;
+}
+
 int rtg_mesh_sizes(const rtg_mesh *mesh, uint64_t *n_nodes, uint64_t *n_leaves, uint32_t *root, uint32_t *depth) {
     if (!mesh) return fail(nullptr, RTG_E_INVALID, "null mesh");
     if (n_nodes) *n_nodes = mesh->dev.n_nodes;

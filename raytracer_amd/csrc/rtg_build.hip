@@ -380,6 +380,12 @@ __global__ void k_emit_leaves(const double *__restrict__ tris, const double *__r
     leaf_source[p] = id;
 }
 
+__global__ void k_gather_leaf_info(const rtg_patch_leaf *__restrict__ by_facet, const uint32_t *__restrict__ leaf_source,
+                                   uint32_t n, rtg_patch_leaf *__restrict__ by_leaf) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) by_leaf[p] = by_facet[leaf_source[p]];
+}
+
 struct Buffers {
     std::vector<void *> owned;
     ~Buffers() {
@@ -411,6 +417,13 @@ inline uint32_t grid_for(uint64_t n) { return (uint32_t)((n + 255) / 256); }
             return e_;                                                                                                 \
         }                                                                                                              \
     } while (0)
+
+hipError_t launch_gather_leaf_info(hipStream_t stream, const rtg_patch_leaf *by_facet, const uint32_t *leaf_source,
+                                   uint32_t n, rtg_patch_leaf *by_leaf) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_leaf_info, dim3(grid_for(n)), dim3(256), 0, stream, by_facet, leaf_source, n, by_leaf);
+    return hipGetLastError();
+}
 
 hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uint32_t n, const double *d_normals_in,
                                   BuiltMesh *out, std::string &err) {

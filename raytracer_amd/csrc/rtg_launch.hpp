@@ -89,6 +89,10 @@ struct BuiltMesh {
 hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uint32_t n, const double *d_normals_in,
                                   BuiltMesh *out, std::string &err);
 
+// by_leaf[l] = by_facet[leaf_source[l]]: per-facet patch records put into leaf order after a device build.
+hipError_t launch_gather_leaf_info(hipStream_t stream, const rtg_patch_leaf *by_facet, const uint32_t *leaf_source,
+                                   uint32_t n, rtg_patch_leaf *by_leaf);
+
 hipError_t launch_selftest_div(hipStream_t stream, uint64_t seed, uint32_t blocks, uint32_t per_thread, uint32_t family,
                                uint64_t *out3);
 

@@ -116,6 +116,7 @@ _sig(lib.rtg_mesh_create, C.c_int, _vp, C.POINTER(Bvh), C.POINTER(_vp))
 _sig(lib.rtg_mesh_create_patches, C.c_int, _vp, C.POINTER(Bvh), C.POINTER(PatchSet), C.POINTER(_vp))
 _sig(lib.rtg_mesh_destroy, None, _vp)
 _sig(lib.rtg_mesh_build, C.c_int, _vp, _vp, C.c_uint64, _vp, C.POINTER(_vp))
+_sig(lib.rtg_mesh_build_patches, C.c_int, _vp, _vp, C.c_uint64, C.POINTER(PatchSet), C.POINTER(_vp))
 _sig(lib.rtg_mesh_sizes, C.c_int, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
      C.POINTER(C.c_uint32))
 _sig(lib.rtg_mesh_read_bvh, C.c_int, _vp, _vp, _vp, _vp)
@@ -454,6 +455,25 @@ class Mesh:
         h = _vp()
         ctx._check(lib.rtg_mesh_build(ctx._h, _ptr(addr), n, _ptr(vertex_normals), C.byref(h)))
         self._keep = keep
+        self._h = h
+        self.ctx = ctx
+        return self
+
+    @classmethod
+    def build_patches(cls, ctx, patches, k=4, newton_steps=5):
+        """Patches tessellated into k*k facets each, the facet tree built on the GPU."""
+        self = cls.__new__(cls)
+        patches = np.ascontiguousarray(patches, dtype=np.float64).reshape(-1, 10, 3)
+        tris, info = patches_tessellate(patches, k)
+        info = np.ascontiguousarray(info)
+        ps = PatchSet()
+        ps.patches = patches.ctypes.data
+        ps.n_patches = patches.shape[0]
+        ps.leaf_info = info.ctypes.data
+        ps.newton_steps = newton_steps
+        h = _vp()
+        ctx._check(lib.rtg_mesh_build_patches(ctx._h, _ptr(tris), tris.shape[0], C.byref(ps), C.byref(h)))
+        self._keep = None
         self._h = h
         self.ctx = ctx
         return self

@@ -141,3 +141,24 @@ def test_million_triangle_build(gpu_ctx):
     assert nodes.tobytes() == host.nodes().tobytes()
     assert leaves.tobytes() == host.leaves().tobytes()
     assert mesh.sizes() == (host.n_nodes, host.n_leaves, host.root, host.depth)
+
+
+def test_patch_set_built_on_the_device(gpu_ctx):
+    patches = rtg.patch_terrain(12, 9, seed=4, scale=1.0)
+    host = rtg.HostPatchMesh(patches, k=3, newton_steps=5)
+    built = rtg.Mesh.build_patches(gpu_ctx, patches, k=3, newton_steps=5)
+    reference = gpu_ctx.mesh(host)
+    assert built.read_bvh()[0].tobytes() == host.bvh.nodes().tobytes()
+    lo, hi = host.bvh.bounds()[:3], host.bvh.bounds()[3:]
+    view = rtg.make_view(orig=(float((lo[0] + hi[0]) / 2), float((lo[1] + hi[1]) / 2), float(hi[2] + (hi - lo).max())))
+    rays = rtg.bench_mesh_rays(np.concatenate([lo - 0.1, hi + 0.1]), 4096, seed=11)
+    out = []
+    for m in (built, reference):
+        sc = gpu_ctx.scene([rtg.patch_object(m, rtg.material((0.5, 0.5, 0.5)))])
+        h1, p1, _ = sc.render_primary(view, 128, 96, points=True)
+        h2, p2, _ = sc.trace(rays, points=True)
+        out.append((h1, p1, h2, p2))
+        sc.close()
+    for a, b in zip(*out):
+        assert a.tobytes() == b.tobytes()
+    assert (out[0][0]["leaf"] != 0xFFFFFFFF).mean() > 0.2
