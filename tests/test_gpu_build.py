@@ -87,6 +87,24 @@ def test_device_built_tree_equals_host_built_tree(gpu_ctx, name, tris):
     reference.close()
 
 
+def test_random_meshes_of_many_sizes(gpu_ctx):
+    """Sizes around the sort's internal block boundaries, with and without coordinate ties."""
+    rng = np.random.default_rng(99)
+    sizes = [6, 7, 8, 9, 31, 33, 127, 129, 255, 256, 257, 511, 513, 1023, 1025, 2047, 2049, 4095, 4097, 8191, 8193,
+             16385, 40000, 70001]
+    for n in sizes + [int(x) for x in rng.integers(10, 30000, size=16)]:
+        for quantum in (0.0, 0.125, 1.0):
+            tris = _soup(n, int(rng.integers(1 << 30)), quantum)
+            host = rtg.HostBvh(tris)
+            mesh = gpu_ctx.build_mesh(tris)
+            nodes, leaves, source = mesh.read_bvh()
+            assert np.array_equal(source, host.leaf_source()), (n, quantum)
+            assert nodes.tobytes() == host.nodes().tobytes(), (n, quantum)
+            assert mesh.sizes() == (host.n_nodes, host.n_leaves, host.root, host.depth), (n, quantum)
+            mesh.close()
+            host.close()
+
+
 def test_trivial_and_invalid_inputs(gpu_ctx):
     empty = gpu_ctx.build_mesh(np.zeros((0, 3, 3)))
     host = rtg.HostBvh(np.zeros((0, 3, 3)))
