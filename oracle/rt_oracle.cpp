@@ -755,6 +755,59 @@ BvhTree subdivide(std::vector<BvhTree> trees) {                                 
     return node;
 }
 
+// ---- tree/bvh_cluster.rs:42-116, tree/bvh_joint.rs:3-8 ------------------------
+// contract_once by its definition, without the k-d tree and the priority queue: while two or more trees remain,
+// the tree whose nearest remaining neighbour (smallest union surface area, bv_kd_tree.rs:34-36) is farthest is
+// taken (the reference pops the maximum, bvh_cluster.rs:67) and joined with that neighbour, popped tree first
+// (bvh_cluster.rs:103-109); the forest becomes the pairs in the order made, then the odd tree out
+// (bvh_cluster.rs:111-115).  Equal distances: the lower index wins both choices (the reference's own order there
+// depends on the internals of the priority-queue crate and of select_nth_unstable: parity unpinned for ties).
+void contract_once(std::vector<BvhTree> &trees) {
+    const size_t n = trees.size();
+    if (n < 2) return;
+    std::vector<char> done(n, 0);
+    std::vector<size_t> head(n, n);
+    std::vector<double> head_distance(n, 0.0);
+    auto find_head = [&](size_t i) {
+        head[i] = n;
+        for (size_t j = 0; j < n; j++) {
+            if (j == i || done[j]) continue;
+            double d = bounds_surface_area(bounds_union(trees[i].bounds, trees[j].bounds));
+            if (head[i] == n || d < head_distance[i]) {
+                head[i] = j;
+                head_distance[i] = d;
+            }
+        }
+    };
+    for (size_t i = 0; i < n; i++) find_head(i);
+    std::vector<std::pair<size_t, size_t>> contractions;
+    size_t remaining = n;
+    while (remaining >= 2) {
+        size_t n1 = n;
+        for (size_t i = 0; i < n; i++)
+            if (!done[i] && (n1 == n || head_distance[i] > head_distance[n1])) n1 = i;
+        size_t n2 = head[n1];
+        done[n1] = done[n2] = 1;
+        remaining -= 2;
+        contractions.emplace_back(n1, n2);
+        if (remaining >= 2)
+            for (size_t i = 0; i < n; i++)
+                if (!done[i] && (head[i] == n1 || head[i] == n2)) find_head(i);
+    }
+    std::vector<BvhTree> next;
+    for (auto &c : contractions) {
+        BvhTree node;
+        node.bounds = bounds_union(node.bounds, trees[c.first].bounds);             // add_node (bvh.rs:72-75)
+        node.nodes.push_back(std::move(trees[c.first]));
+        node.bounds = bounds_union(node.bounds, trees[c.second].bounds);
+        node.nodes.push_back(std::move(trees[c.second]));
+        next.push_back(std::move(node));
+    }
+    for (size_t i = 0; i < n; i++)
+        if (!done[i]) next.push_back(std::move(trees[i]));
+    trees = std::move(next);
+}
+
 uint32_t depth_of(const orc_bvh &b, uint32_t node) {
     uint32_t d = 0;
     const rtg_bvh_node &n = b.nodes[node];
@@ -1176,13 +1229,23 @@ void orc_dielectric(const double inc[3], const double sn[3], double n1, double n
 }
 
 orc_bvh *orc_bvh_build_subdivide(const rtg_tri *tris, uint64_t n, const double *vertex_normals) {
+    return orc_bvh_build(tris, n, vertex_normals, 0);
+}
+orc_bvh *orc_bvh_build(const rtg_tri *tris, uint64_t n, const double *vertex_normals, int strategy) {
     std::vector<BvhTree> forest((size_t)n);                                     // BvhForest::new (bvh.rs:48-58)
     for (uint64_t i = 0; i < n; i++) {
         TriVerts tv = leaf_tri(tris[i]);
         forest[i].bounds = bounds_union(forest[i].bounds, triangle_bounds(tv.p)); // add_leaf (bvh.rs:68-71)
         forest[i].leaves.push_back((uint32_t)i);
     }
-    BvhTree tree = subdivide(std::move(forest));
+    BvhTree tree;
+    if (strategy == 1) {                                                        // contract (bvh_cluster.rs:43-48)
+        while (forest.size() > 1) contract_once(forest);
+        if (!forest.empty()) tree = std::move(forest[0]);
+    } else {
+        if (strategy == 2) contract_once(forest);                               // hybrid (bvh_joint.rs:4-7)
+        tree = subdivide(std::move(forest));
+    }
     orc_bvh *b = new orc_bvh();                                                 // Bvh::new (bvh.rs:80-90)
     rtg_bvh_node root = add_bvh_tree(*b, tree, tris, vertex_normals);
     b->root = (uint32_t)b->nodes.size();

@@ -72,6 +72,9 @@ void orc_dielectric(const double inc[3], const double signed_norm[3], double n1,
 /* ---- BVH --------------------------------------------------------------- */
 /* BvhForest::new(tris).subdivide() then Bvh::new(&tree). */
 orc_bvh *orc_bvh_build_subdivide(const rtg_tri *tris, uint64_t n, const double *vertex_normals);
+/* strategy 0: subdivide; 1: BvhForest::contract (tree/bvh_cluster.rs:43-48); 2: BvhForest::hybrid
+ * (tree/bvh_joint.rs:3-8).  The pairing is evaluated by its definition in O(n^3): small inputs only. */
+orc_bvh *orc_bvh_build(const rtg_tri *tris, uint64_t n, const double *vertex_normals, int strategy);
 /* Wrap already-flattened arrays (copied). */
 orc_bvh *orc_bvh_from_flat(const rtg_bvh *flat);
 void orc_bvh_destroy(orc_bvh *b);

@@ -48,4 +48,10 @@ struct Bvh {
 // (capped at 16).
 Bvh build_subdivide(const rtg_tri *tris, uint64_t n, const double *vertex_normals, int threads);
 
+// BvhForest::new(tris).contract() / .hybrid() followed by Bvh::new (tree/bvh_cluster.rs:42-116,
+// tree/bvh_joint.rs:3-8); see rt_bvh_cluster.cpp for the rule applied where the reference's choice among equal
+// distances is not restatable.
+Bvh build_contract(const rtg_tri *tris, uint64_t n, const double *vertex_normals, int threads);
+Bvh build_hybrid(const rtg_tri *tris, uint64_t n, const double *vertex_normals, int threads);
+
 } // namespace rt

@@ -21,6 +21,16 @@ rth_bvh *rth_bvh_build_subdivide(const rtg_tri *tris, uint64_t n, const double *
     b->bvh = rt::build_subdivide(tris, n, vertex_normals, threads);
     return b;
 }
+rth_bvh *rth_bvh_build(const rtg_tri *tris, uint64_t n, const double *vertex_normals, int threads, int strategy) {
+    rth_bvh *b = new rth_bvh();
+    if (strategy == 1)
+        b->bvh = rt::build_contract(tris, n, vertex_normals, threads);
+    else if (strategy == 2)
+        b->bvh = rt::build_hybrid(tris, n, vertex_normals, threads);
+    else
+        b->bvh = rt::build_subdivide(tris, n, vertex_normals, threads);
+    return b;
+}
 void rth_bvh_destroy(rth_bvh *b) { delete b; }
 void rth_bvh_view(const rth_bvh *b, rtg_bvh *out) { *out = b->bvh.view(); }
 const uint32_t *rth_bvh_leaf_source(const rth_bvh *b) { return b->bvh.leaf_source.data(); }

@@ -12,6 +12,8 @@ typedef struct rth_bvh rth_bvh;
 
 /* BvhForest::new(tris).subdivide() + Bvh::new (src/tree/bvh_subdivide.rs, src/tree/bvh.rs:80-106) */
 rth_bvh *rth_bvh_build_subdivide(const rtg_tri *tris, uint64_t n, const double *vertex_normals, int threads);
+/* strategy 0: BvhForest::subdivide, 1: BvhForest::contract, 2: BvhForest::hybrid. */
+rth_bvh *rth_bvh_build(const rtg_tri *tris, uint64_t n, const double *vertex_normals, int threads, int strategy);
 void rth_bvh_destroy(rth_bvh *b);
 void rth_bvh_view(const rth_bvh *b, rtg_bvh *out);
 const uint32_t *rth_bvh_leaf_source(const rth_bvh *b);

@@ -130,6 +130,7 @@ _sig(lib.rtg_render_frame, C.c_int, _vp, C.POINTER(View), _vp, C.c_uint32, C.c_u
      C.c_uint32, _vp, _vp, _vp)
 
 _sig(host.rth_bvh_build_subdivide, _vp, _vp, C.c_uint64, _vp, C.c_int)
+_sig(host.rth_bvh_build, _vp, _vp, C.c_uint64, _vp, C.c_int, C.c_int)
 _sig(host.rth_bvh_destroy, None, _vp)
 _sig(host.rth_bvh_view, None, _vp, C.POINTER(Bvh))
 _sig(host.rth_bvh_leaf_source, C.POINTER(C.c_uint32), _vp)
@@ -285,15 +286,18 @@ def copy_object(o):
     return c
 
 
+BUILD_STRATEGIES = {"subdivide": 0, "contract": 1, "hybrid": 2}
+
+
 class HostBvh:
-    """BvhForest::new(tris).subdivide() + Bvh::new -- flattened on the host."""
+    """BvhForest::new(tris).subdivide() (or .contract() / .hybrid()) + Bvh::new -- flattened on the host."""
     _h = None
 
-    def __init__(self, tris, vertex_normals=None, threads=0):
+    def __init__(self, tris, vertex_normals=None, threads=0, strategy="subdivide"):
         tris = np.ascontiguousarray(tris, dtype=np.float64).reshape(-1, 3, 3)
         self._tris = tris
         self._normals = None if vertex_normals is None else np.ascontiguousarray(vertex_normals, dtype=np.float64)
-        self._h = host.rth_bvh_build_subdivide(_ptr(tris), tris.shape[0], _ptr(self._normals), threads)
+        self._h = host.rth_bvh_build(_ptr(tris), tris.shape[0], _ptr(self._normals), threads, BUILD_STRATEGIES[strategy])
         self.view = Bvh()
         host.rth_bvh_view(self._h, C.byref(self.view))
 

@@ -48,6 +48,7 @@ _sig(lib.orc_view_get_ray, None, C.POINTER(rtg.View), _dp, _dp)
 _sig(lib.orc_pixel_ndc, None, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _dp)
 _sig(lib.orc_dielectric, None, _dp, _dp, C.c_double, C.c_double, _dp)
 _sig(lib.orc_bvh_build_subdivide, _vp, _vp, C.c_uint64, _vp)
+_sig(lib.orc_bvh_build, _vp, _vp, C.c_uint64, _vp, C.c_int)
 _sig(lib.orc_bvh_from_flat, _vp, C.POINTER(rtg.Bvh))
 _sig(lib.orc_bvh_destroy, None, _vp)
 _sig(lib.orc_bvh_n_nodes, C.c_uint64, _vp)
@@ -163,14 +164,15 @@ def patches_tessellate(patches, k):
 class OracleBvh:
     _h = None
 
-    def __init__(self, tris=None, vertex_normals=None, flat=None):
+    def __init__(self, tris=None, vertex_normals=None, flat=None, strategy="subdivide"):
         if flat is not None:
             self._keep = flat
             self._h = lib.orc_bvh_from_flat(C.byref(flat))
         else:
             tris = np.ascontiguousarray(tris, dtype=np.float64).reshape(-1, 3, 3)
             vn = None if vertex_normals is None else np.ascontiguousarray(vertex_normals, dtype=np.float64)
-            self._h = lib.orc_bvh_build_subdivide(tris.ctypes.data, tris.shape[0], None if vn is None else vn.ctypes.data)
+            self._h = lib.orc_bvh_build(tris.ctypes.data, tris.shape[0], None if vn is None else vn.ctypes.data,
+                                        rtg.BUILD_STRATEGIES[strategy])
 
     @property
     def handle(self):

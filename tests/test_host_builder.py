@@ -125,3 +125,69 @@ def test_counters_count_every_visited_node():
     # a ray that misses the root box visits exactly one node and no triangle
     hit, ctr = o.raycast([50, 50, 50, 0, 0, 1], counters=True)
     assert hit["leaf"] == rtg.RTG_NONE and ctr["nodes_visited"] == 1 and ctr["tris_tested"] == 0
+
+
+# ---- BvhForest::contract / hybrid (tree/bvh_cluster.rs:42-116, tree/bvh_joint.rs:3-8) ------------------------------
+@pytest.mark.parametrize("strategy", ["contract", "hybrid"])
+@pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (16, 6), (17, 7), (100, 8), (301, 9)])
+def test_pairing_builders_match_the_definition(strategy, n, seed):
+    """k-d tree + priority queue on the host against the oracle's evaluation of the pairing rule by definition."""
+    tris = _random_tris(n, seed)
+    _same_tree(rtg.HostBvh(tris, strategy=strategy), orc.OracleBvh(tris, strategy=strategy))
+
+
+@pytest.mark.parametrize("strategy", ["contract", "hybrid"])
+def test_pairing_builders_with_equal_distances(strategy):
+    """Lattice quads and duplicates: many exactly equal union areas; both implementations apply the same
+    lower-index rule there (the reference's own order among equal distances is not restatable)."""
+    quads = []
+    for y in range(6):
+        for x in range(7):
+            a, b, c, d = (x, y, 0.0), (x + 1.0, y, 0.25), (x + 1.0, y + 1.0, 0.0), (x, y + 1.0, 0.25)
+            quads += [(a, b, c), (a, c, d)]
+    lattice = np.array(quads, dtype=np.float64)
+    _same_tree(rtg.HostBvh(lattice, strategy=strategy), orc.OracleBvh(lattice, strategy=strategy))
+    dup = np.repeat(_random_tris(3, 21), 15, axis=0)
+    _same_tree(rtg.HostBvh(dup, strategy=strategy), orc.OracleBvh(dup, strategy=strategy))
+
+
+def test_contract_once_known_answer():
+    """Four unit-ish boxes on a line at x = 0, 1, 10, 12 (as thin tilted triangles).  Nearest neighbours: 0<->1,
+    10->12, 12->10; the farthest nearest-neighbour distance belongs to the pair (10, 12), and of those two the
+    lower index is popped first, so the forest becomes [(10,12), (0,1)]: leaves in traversal order are the
+    triangles 2, 3, 0, 1."""
+    def tri(x):
+        return [[x, 0.0, 0.0], [x + 1.0, 0.0, 0.5], [x, 1.0, 1.0]]
+    tris = np.array([tri(0.0), tri(1.0), tri(10.0), tri(12.0)])
+    for make in (lambda s: rtg.HostBvh(tris, strategy=s), lambda s: orc.OracleBvh(tris, strategy=s)):
+        assert list(make("contract").leaf_source()) == [2, 3, 0, 1]
+        h = make("hybrid")                                   # pairs, then subdivide sorts them along x
+        assert list(h.leaf_source()) == [0, 1, 2, 3]
+        assert h.n_nodes == 7 and h.depth == 3
+
+
+@pytest.mark.parametrize("strategy", ["contract", "hybrid"])
+def test_pairing_builders_make_valid_trees(strategy):
+    tris = rtg.heightfield(40, 25, seed=8, scale=1.0)         # 2000 triangles: beyond the oracle's O(n^3) budget
+    h = rtg.HostBvh(tris, strategy=strategy)
+    nodes = h.nodes()
+    assert h.n_nodes == 2 * len(tris) - 1 and sorted(h.leaf_source()) == list(range(len(tris)))
+    assert np.array_equal(h.leaves(), tris[h.leaf_source()])
+
+    def walk(i):
+        n = nodes[i]
+        lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+        for l in range(n["leaf_begin"], n["leaf_end"]):
+            lo, hi = np.minimum(lo, h.leaves()[l].min(axis=0)), np.maximum(hi, h.leaves()[l].max(axis=0))
+        for c in range(n["child_begin"], n["child_end"]):
+            clo, chi = walk(c)
+            lo, hi = np.minimum(lo, clo), np.maximum(hi, chi)
+        assert np.array_equal(lo, n["lo"]) and np.array_equal(hi, n["hi"])
+        return lo, hi
+    walk(h.root)
+    # traversal through the tree finds what testing every triangle finds
+    o = orc.OracleBvh(flat=h.view)
+    lo, hi = tris.min(axis=(0, 1)), tris.max(axis=(0, 1))
+    for r in rtg.bench_mesh_rays(np.concatenate([lo, hi]), 500, seed=5):
+        a, b = o.raycast(r), o.raycast_brute(r)
+        assert a["leaf"] == b["leaf"] and (a["t"] == b["t"] or (np.isnan(a["t"]) and np.isnan(b["t"])))
