@@ -1,6 +1,9 @@
 // rt_host_c.cpp -- C wrappers of the host library (see rt_host_c.h).
 #include "rt_host_c.h"
 
+#include <map>
+#include <string>
+
 #include <algorithm>
 #include <cstring>
 #include <numeric>
@@ -114,6 +117,19 @@ int rth_render_scene_builder(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32
 }
 uint64_t rth_to_hdr(const double *rgb, uint32_t width, uint32_t height, uint8_t *out, uint64_t cap) {
     std::vector<uint8_t> b = rt::to_hdr(rgb, width, height);
+    if (out && cap >= b.size()) std::memcpy(out, b.data(), b.size());
+    return b.size();
+}
+uint64_t rth_images_tar(const double *rgb, uint32_t width, uint32_t height, double seconds, uint8_t *out, uint64_t cap) {
+    std::map<std::string, std::vector<uint8_t>> images;                    // Renderer::images (renderer.rs:379-385)
+    const size_t n = (size_t)width * height * 3;
+    images["image.hdr"] = rt::to_hdr(rgb, width, height);
+    std::vector<double> pq(n);
+    for (size_t i = 0; i < n; i++) pq[i] = rt::smpte2048_encode(rgb[i] / 80.0);
+    images["image.pq.hdr"] = rt::to_hdr(pq.data(), width, height);
+    std::vector<double> perf(n, seconds / ((double)width * height) * 3000.0);
+    images["perf.hdr"] = rt::to_hdr(perf.data(), width, height);
+    std::vector<uint8_t> b = rt::images_tar(images);
     if (out && cap >= b.size()) std::memcpy(out, b.data(), b.size());
     return b.size();
 }

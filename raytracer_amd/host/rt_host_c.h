@@ -42,6 +42,9 @@ void rth_scene_builder(uint64_t time, rtg_object objects[2], rtg_light lights[2]
 int rth_render_scene_builder(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32_t height, uint32_t max_depth,
                              double *out_rgb, rtg_hit *out_hits);
 /* Radiance .hdr bytes of an RGB double image; returns the byte count (call with out == NULL to size). */
+/* The three images of Renderer::images (image.hdr, image.pq.hdr, perf.hdr) of an RGB double frame rendered in
+ * `seconds`, framed as the tar archive the reference's server returns (bin/server.rs:19-30); returns the byte count. */
+uint64_t rth_images_tar(const double *rgb, uint32_t width, uint32_t height, double seconds, uint8_t *out, uint64_t cap);
 uint64_t rth_to_hdr(const double *rgb, uint32_t width, uint32_t height, uint8_t *out, uint64_t cap);
 
 #ifdef __cplusplus

@@ -270,4 +270,36 @@ std::map<std::string, std::vector<uint8_t>> Renderer::images() const {      // r
     return r;
 }
 
+// The archive the reference's server answers with (bin/server.rs:19-30): one GNU-format header per image (path,
+// size, mode 0o700, modification time 0, checksum), the bytes padded to 512, two empty blocks at the end.
+std::vector<uint8_t> images_tar(const std::map<std::string, std::vector<uint8_t>> &images) {
+    std::vector<uint8_t> out;
+    auto octal = [](uint8_t *field, size_t width, uint64_t value) {          // width-1 octal digits and a NUL
+        for (size_t i = width - 1; i-- > 0;) {
+            field[i] = (uint8_t)('0' + (value & 7));
+            value >>= 3;
+        }
+        field[width - 1] = 0;
+    };
+    for (const auto &kv : images) {
+        uint8_t h[512] = {0};
+        std::memcpy(h, kv.first.data(), std::min<size_t>(kv.first.size(), 100));
+        octal(h + 100, 8, 0700);
+        octal(h + 124, 12, kv.second.size());
+        octal(h + 136, 12, 0);
+        std::memcpy(h + 257, "ustar ", 6);
+        h[263] = ' ';
+        h[264] = 0;
+        std::memset(h + 148, ' ', 8);
+        uint32_t sum = 0;
+        for (int i = 0; i < 512; i++) sum += h[i];
+        octal(h + 148, 8, sum);
+        out.insert(out.end(), h, h + 512);
+        out.insert(out.end(), kv.second.begin(), kv.second.end());
+        out.resize((out.size() + 511) / 512 * 512, 0);
+    }
+    out.resize(out.size() + 1024, 0);
+    return out;
+}
+
 } // namespace rt

@@ -139,6 +139,8 @@ std::shared_ptr<GpuMesh> upload_mesh(rtg_ctx *ctx, Bvh bvh);
 // Radiance RGBE (.hdr) writer for a row-major RGB double image; NaN pixels
 // become the reference's checkerboard (render/image.rs:44-66).
 std::vector<uint8_t> to_hdr(const double *rgb, uint32_t width, uint32_t height);
+// The tar archive of Renderer::images() as the reference's server frames it (bin/server.rs:19-30).
+std::vector<uint8_t> images_tar(const std::map<std::string, std::vector<uint8_t>> &images);
 double smpte2048_encode(double x);   // geo/color.rs:15-17
 
 } // namespace rt

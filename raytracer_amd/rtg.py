@@ -146,6 +146,7 @@ _sig(host.rth_transform_build, None, C.c_double, C.POINTER(C.c_double), C.POINTE
 _sig(host.rth_scene_builder, None, C.c_uint64, C.POINTER(Object), C.POINTER(Light), C.POINTER(View))
 _sig(host.rth_render_scene_builder, C.c_int, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp)
 _sig(host.rth_to_hdr, C.c_uint64, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64)
+_sig(host.rth_images_tar, C.c_uint64, _vp, C.c_uint32, C.c_uint32, C.c_double, _vp, C.c_uint64)
 
 
 def _ptr(a):
@@ -657,4 +658,13 @@ def to_hdr(rgb, width, height):
     n = host.rth_to_hdr(_ptr(rgb), width, height, None, 0)
     out = np.empty(n, dtype=np.uint8)
     host.rth_to_hdr(_ptr(rgb), width, height, _ptr(out), n)
+    return out.tobytes()
+
+
+def images_tar(rgb, width, height, seconds=0.0):
+    """Renderer::images() framed as the reference server's tar archive."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    n = host.rth_images_tar(_ptr(rgb), width, height, seconds, None, 0)
+    out = np.empty(n, dtype=np.uint8)
+    host.rth_images_tar(_ptr(rgb), width, height, seconds, _ptr(out), n)
     return out.tobytes()
