@@ -194,6 +194,21 @@ typedef struct {
     uint32_t tris_tested;
 } rtg_ray_counters;
 
+/* One `SpecularPath` (src/render/renderer.rs:93-103): the hit a ray of a batch reaches after `depth` specular
+ * bounces.  `modes` bit i is set when bounce i was `SpecularMode::Refract`, clear for `Reflect`
+ * (`modes.len()` = depth); `attenuation` is the product of the Fresnel factors along the way; the reference's
+ * `manifolds` are the `point.manifold` of the ancestors, found by following `parent` (index in the same output
+ * array of the path that ends on the surface this one bounced off last; RTG_NONE at depth 0). */
+typedef struct {
+    uint32_t ray;
+    uint32_t depth;
+    uint32_t modes;
+    uint32_t parent;
+    double attenuation;
+    double _pad;
+    rtg_point point;
+} rtg_path;
+
 /* ---- context ---------------------------------------------------------- */
 
 /* No reference counterpart (the reference is CPU-only): binds a HIP device. */
@@ -285,6 +300,16 @@ int rtg_render_primary(rtg_scene *scene, const rtg_view *view, uint32_t width, u
  * orig.xyz, dir.xyz per ray.  out_points / out_counters may be NULL. */
 int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *out_hits,
               rtg_point *out_points, rtg_ray_counters *out_counters);
+
+/* Batched `Renderer::raytrace_all_specular(&ray, &[], None)` (src/render/renderer.rs:284-378): every hit of every
+ * ray's specular path tree (reflection and refraction at each dielectric hit, at most `max_depth` surface
+ * interactions per path; the reference's constant is 4, renderer.rs:312).  Paths are written in ray order and,
+ * within a ray, in the order the recursion emits them.  What the photon pass (renderer.rs:119-138) and, with
+ * photons enabled, the pixel pass (renderer.rs:266-278) iterate over.  `capacity` is the room in out_paths;
+ * *n_paths receives the number of paths; when it exceeds `capacity` nothing is written and RTG_E_LIMIT is
+ * returned (n_rays * (2^max_depth - 1) always suffices). */
+int rtg_trace_paths(rtg_scene *scene, const double *rays6, uint64_t n_rays, uint32_t max_depth,
+                    rtg_path *out_paths, uint64_t capacity, uint64_t *n_paths);
 
 /* `compute_direct_irrad` x `material.diffuse` (src/render/renderer.rs:184-205,
  * 270-277) for n hit points (one shadow ray per light, closest-hit query).

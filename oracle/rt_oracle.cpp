@@ -1019,22 +1019,26 @@ V3 compute_direct_irrad(const orc_scene &s, const rtg_light *lights, uint32_t nl
 struct PathPoint {
     RaycastPoint point;
     double attenuation;
+    uint32_t depth, modes, parent;   // output_modes as bits (1 = Refract), index of the path bounced off last
 };
 // raytrace_all_specular_rec (renderer.rs:296-378) with no filters; `depth` is
 // output_manifolds.len(), `max_depth` the reference's constant 4 (renderer.rs:312).
 void all_specular_rec(const orc_scene &s, const Ray &ray, double attenuation, uint32_t depth,
-                      uint32_t max_depth, std::vector<PathPoint> &output, Counters &ctr) {
+                      uint32_t max_depth, std::vector<PathPoint> &output, Counters &ctr, uint32_t modes = 0,
+                      uint32_t parent = RTG_NONE) {
     if (depth >= max_depth) return;
     RaycastPoint first;
     if (!scene_raycast(s, ray, first, ctr)) return;
-    output.push_back(PathPoint{first, attenuation});
+    const uint32_t self = (uint32_t)output.size();
+    output.push_back(PathPoint{first, attenuation, depth, modes, parent});
     if (first.material.has_dielectric) {
         Dielectric di = dielectric_new(ray.dir, first.geo_normal, first.material.n1, first.material.n2);
         Ray reflect = new_bounce(first.position, di.reflect);
-        all_specular_rec(s, reflect, attenuation * di.reflectance, depth + 1, max_depth, output, ctr);
+        all_specular_rec(s, reflect, attenuation * di.reflectance, depth + 1, max_depth, output, ctr, modes, self);
         if (di.has_refract) {
             Ray refract = new_bounce(first.position, di.refract);
-            all_specular_rec(s, refract, attenuation * (1.0 - di.reflectance), depth + 1, max_depth, output, ctr);
+            all_specular_rec(s, refract, attenuation * (1.0 - di.reflectance), depth + 1, max_depth, output, ctr,
+                             modes | (1u << depth), self);
         }
     }
 }
@@ -1407,6 +1411,30 @@ int orc_trace(const orc_scene *s, const double *rays6, uint64_t n, rtg_hit *out_
         }
     });
     return 0;
+}
+int orc_trace_paths(const orc_scene *s, const double *rays6, uint64_t n, uint32_t max_depth, rtg_path *out,
+                    uint64_t capacity, uint64_t *n_paths) {
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        std::vector<PathPoint> paths;
+        Counters c;
+        all_specular_rec(*s, ray_from6(rays6 + i * 6), 1.0, 0, max_depth, paths, c);
+        for (const PathPoint &pp : paths) {
+            if (total < capacity) {
+                rtg_path &o = out[total];
+                std::memset(&o, 0, sizeof(o));
+                o.ray = (uint32_t)i;
+                o.depth = pp.depth;
+                o.modes = pp.modes;
+                o.parent = pp.parent == RTG_NONE ? RTG_NONE : (uint32_t)(total - (&pp - paths.data()) + pp.parent);
+                o.attenuation = pp.attenuation;
+                point_to_c(true, pp.point, nullptr, &o.point);
+            }
+            total++;
+        }
+    }
+    *n_paths = total;
+    return total <= capacity ? 0 : -1;
 }
 int orc_shade_direct(const orc_scene *s, const rtg_light *lights, uint32_t n_lights,
                      const rtg_point *points, uint64_t n, double *rgb_out, uint8_t *rgba8_out, int threads) {

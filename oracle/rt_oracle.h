@@ -111,6 +111,9 @@ int orc_render_primary(const orc_scene *s, const rtg_view *view, uint32_t width,
                        rtg_ray_counters *out_counters, int threads);
 int orc_trace(const orc_scene *s, const double *rays6, uint64_t n, rtg_hit *out_hits,
               rtg_point *out_points, rtg_ray_counters *out_counters, int threads);
+/* raytrace_all_specular(&ray, &[], None) per ray (renderer.rs:284-378), paths concatenated in ray order. */
+int orc_trace_paths(const orc_scene *s, const double *rays6, uint64_t n, uint32_t max_depth, rtg_path *out,
+                    uint64_t capacity, uint64_t *n_paths);
 int orc_shade_direct(const orc_scene *s, const rtg_light *lights, uint32_t n_lights,
                      const rtg_point *points, uint64_t n, double *rgb_out, uint8_t *rgba8_out,
                      int threads);

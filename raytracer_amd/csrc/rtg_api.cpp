@@ -1024,6 +1024,123 @@ int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *o
     return RTG_OK;
 }
 
+int rtg_trace_paths(rtg_scene *scene, const double *rays6, uint64_t n_rays, uint32_t max_depth, rtg_path *out_paths,
+                    uint64_t capacity, uint64_t *n_paths) {
+    int rc = check_scene_call(scene);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = scene->ctx;
+    if (!n_paths) return fail(ctx, RTG_E_INVALID, "rtg_trace_paths: n_paths is null");
+    *n_paths = 0;
+    if (max_depth < 1 || max_depth > 8) return fail(ctx, RTG_E_INVALID, "rtg_trace_paths: max_depth must be 1..8");
+    if (n_rays == 0) return RTG_OK;
+    if (!rays6) return fail(ctx, RTG_E_INVALID, "rtg_trace_paths: rays6 is null");
+    if (capacity && !out_paths) return fail(ctx, RTG_E_INVALID, "rtg_trace_paths: out_paths is null");
+    if (n_rays >= (1ull << 31)) return fail(ctx, RTG_E_LIMIT, "rtg_trace_paths: too many rays for one call");
+    if ((uintptr_t)rays6 % 16 != 0 && is_device_pointer(rays6))
+        return fail(ctx, RTG_E_INVALID, "rtg_trace_paths: device ray buffer must be 16-byte aligned");
+    const void *d_rays0 = nullptr;
+    if ((rc = in_prepare(ctx, "in_rays", rays6, n_rays * 6 * sizeof(double), &d_rays0)) != RTG_OK) return rc;
+
+    void *v = nullptr;
+    if ((rc = scratch_get(ctx, "path_counters", 4 * sizeof(uint32_t), &v)) != RTG_OK) return rc;
+    uint32_t *cnt = (uint32_t *)v;            // [0] rays spawned, [1] unused, [2] refracting hits, [3] records of the level
+    uint32_t host_cnt[4] = {0, 0, 0, 0};
+    auto read_counters = [&]() -> int {
+        HIP_TRY(ctx, hipMemcpyAsync(host_cnt, cnt, sizeof(host_cnt), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return RTG_OK;
+    };
+    const rtg_path *level_records[8];
+    const uint64_t *level_keys[8];
+    uint32_t level_first[9], level_count[8];
+    uint32_t n_levels = 0;
+    uint64_t total = 0;
+    const double *d_rays = (const double *)d_rays0;
+    uint64_t m = n_rays;
+    const rtg_view no_view{};
+    const rtg_rect no_tile{};
+    for (uint32_t depth = 0; depth < max_depth && m != 0; depth++) {
+        const std::string tag = std::to_string(depth);
+        void *meta = nullptr, *pts = nullptr, *hits = nullptr, *keys = nullptr, *recs = nullptr;
+        if (depth == 0) {
+            if ((rc = scratch_get(ctx, "path_meta_0", m * sizeof(SpecMeta), &meta)) != RTG_OK) return rc;
+            HIP_TRY(ctx, launch_path_roots(ctx->stream, m, (SpecMeta *)meta));
+        } else {
+            meta = ctx->scratch["path_meta_" + tag].ptr;
+        }
+        if ((rc = scratch_get(ctx, "path_points", m * sizeof(rtg_point), &pts)) != RTG_OK) return rc;
+        if ((rc = scratch_get(ctx, "path_hits", m * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
+        if ((rc = scratch_get(ctx, ("path_keys_" + tag).c_str(), m * sizeof(uint64_t), &keys)) != RTG_OK) return rc;
+        if ((rc = scratch_get(ctx, ("path_records_" + tag).c_str(), m * sizeof(rtg_path), &recs)) != RTG_OK) return rc;
+        DevScene ds;
+        if ((rc = scene_for_launch(scene, (m + kBlock - 1) / kBlock * kBlock, ds)) != RTG_OK) return rc;
+        if (ctx->traversal == 2) {
+            PhasedScratch ps;
+            if ((rc = phased_scratch(ctx, ds, m, ps)) != RTG_OK) return rc;
+            HIP_TRY(ctx, launch_trace_phased(ctx->stream, ds, d_rays, m, ps, ctx->tune, (rtg_hit *)hits, nullptr));
+            HIP_TRY(ctx, launch_points_batch(ctx->stream, ds, d_rays, m, (const rtg_hit *)hits, (rtg_point *)pts));
+        } else {
+            HIP_TRY(ctx, launch_trace(ctx->stream, ds, d_rays, m, (rtg_hit *)hits, (rtg_point *)pts, nullptr));
+        }
+        HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 4 * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, launch_path_emit(ctx->stream, (const SpecMeta *)meta, (const rtg_point *)pts, m, max_depth, cnt + 3,
+                                      (uint64_t *)keys, (rtg_path *)recs));
+        const bool deeper = depth + 1 < max_depth;
+        if (deeper) HIP_TRY(ctx, launch_spec_count(ctx->stream, ds, (const rtg_point *)pts, m, cnt + 2));
+        if ((rc = read_counters()) != RTG_OK) return rc;
+        level_records[n_levels] = (const rtg_path *)recs;
+        level_keys[n_levels] = (const uint64_t *)keys;
+        level_first[n_levels] = (uint32_t)total;
+        level_count[n_levels] = host_cnt[3];
+        n_levels++;
+        total += host_cnt[3];
+        if (total >= (1ull << 32)) return fail(ctx, RTG_E_LIMIT, "rtg_trace_paths: more than 2^32 paths");
+        uint64_t m_next = 0;
+        const uint32_t k = host_cnt[2];
+        if (deeper && k != 0) {
+            const std::string next_tag = std::to_string(depth + 1);
+            void *next_rays = nullptr, *next_meta = nullptr;
+            if ((rc = scratch_get(ctx, ("path_rays_" + next_tag).c_str(), (size_t)k * 2 * 6 * sizeof(double), &next_rays)) != RTG_OK) return rc;
+            if ((rc = scratch_get(ctx, ("path_meta_" + next_tag).c_str(), (size_t)k * 2 * sizeof(SpecMeta), &next_meta)) != RTG_OK) return rc;
+            HIP_TRY(ctx, launch_spec_spawn(ctx->stream, ds, no_view, 0, 0, no_tile, d_rays, (const SpecMeta *)meta,
+                                           (const rtg_point *)pts, m, depth, max_depth, (double *)next_rays,
+                                           (SpecMeta *)next_meta, nullptr, cnt));
+            if ((rc = read_counters()) != RTG_OK) return rc;
+            m_next = host_cnt[0];
+            d_rays = (const double *)next_rays;
+        }
+        m = m_next;
+    }
+    *n_paths = total;
+    if (total > capacity)
+        return fail(ctx, RTG_E_LIMIT, "rtg_trace_paths: %llu paths, room for %llu", (unsigned long long)total,
+                    (unsigned long long)capacity);
+    if (total == 0) return RTG_OK;
+
+    uint32_t ray_bits = 1;
+    while ((1ull << ray_bits) < n_rays) ray_bits++;
+    const uint32_t key_bits = 8 + ray_bits;
+    void *keys_all = nullptr, *keys_sorted = nullptr, *source = nullptr, *source_sorted = nullptr, *temp = nullptr;
+    const size_t temp_bytes = path_sort_temp_bytes((uint32_t)total, key_bits);
+    if ((rc = scratch_get(ctx, "path_keys_all", total * sizeof(uint64_t), &keys_all)) != RTG_OK) return rc;
+    if ((rc = scratch_get(ctx, "path_keys_sorted", total * sizeof(uint64_t), &keys_sorted)) != RTG_OK) return rc;
+    if ((rc = scratch_get(ctx, "path_source", total * sizeof(uint32_t), &source)) != RTG_OK) return rc;
+    if ((rc = scratch_get(ctx, "path_source_sorted", total * sizeof(uint32_t), &source_sorted)) != RTG_OK) return rc;
+    if ((rc = scratch_get(ctx, "path_sort_temp", temp_bytes, &temp)) != RTG_OK) return rc;
+    for (uint32_t l = 0; l < n_levels; l++)
+        if (level_count[l])
+            HIP_TRY(ctx, hipMemcpyAsync((uint64_t *)keys_all + level_first[l], level_keys[l],
+                                        (size_t)level_count[l] * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    Out op;
+    if ((rc = out_prepare(ctx, "out_paths", out_paths, total * sizeof(rtg_path), op)) != RTG_OK) return rc;
+    HIP_TRY(ctx, launch_path_sort_gather(ctx->stream, level_records, level_first, n_levels, (uint32_t)total, key_bits,
+                                         (const uint64_t *)keys_all, (uint64_t *)keys_sorted, (uint32_t *)source,
+                                         (uint32_t *)source_sorted, temp, temp_bytes, (rtg_path *)op.dev));
+    if ((rc = out_finish(ctx, op)) != RTG_OK) return rc;
+    if (op.staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTG_OK;
+}
+
 namespace {
 // compute_direct_irrad for device-resident points through the persistent kernel: one closest-hit launch over all
 // (light, point) shadow rays -- and, in the same launch, over `n_rays` further rays whose hits land behind the

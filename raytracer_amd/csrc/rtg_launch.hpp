@@ -93,6 +93,17 @@ hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uin
 hipError_t launch_gather_leaf_info(hipStream_t stream, const rtg_patch_leaf *by_facet, const uint32_t *leaf_source,
                                    uint32_t n, rtg_patch_leaf *by_leaf);
 
+// Path records of a ray batch (rtg_paths.hip): root meta, one record per hit of a level, and the final ordering
+// by (ray, pre-order index) with parents resolved to positions.
+hipError_t launch_path_roots(hipStream_t stream, uint64_t n, SpecMeta *meta);
+hipError_t launch_path_emit(hipStream_t stream, const SpecMeta *meta, const rtg_point *points, uint64_t n,
+                            uint32_t max_depth, uint32_t *counter, uint64_t *keys, rtg_path *records);
+size_t path_sort_temp_bytes(uint32_t n, uint32_t key_bits);
+hipError_t launch_path_sort_gather(hipStream_t stream, const rtg_path *const *level_records, const uint32_t *level_first,
+                                   uint32_t n_levels, uint32_t n, uint32_t key_bits, const uint64_t *keys,
+                                   uint64_t *keys_sorted, uint32_t *source, uint32_t *source_sorted, void *temp,
+                                   size_t temp_bytes, rtg_path *out);
+
 hipError_t launch_selftest_div(hipStream_t stream, uint64_t seed, uint32_t blocks, uint32_t per_thread, uint32_t family,
                                uint64_t *out3);
 

@@ -82,6 +82,8 @@ HIT_DTYPE = np.dtype([("object", "<u4"), ("leaf", "<u4"), ("t", "<f8")])
 POINT_DTYPE = np.dtype([("time", "<f8"), ("position", "<f8", 3), ("inter_normal", "<f8", 3),
                         ("geo_normal", "<f8", 3), ("manifold_point", "<f8", 2), ("manifold", "<u4", 2),
                         ("manifold_len", "<u4"), ("material_slot", "<u4")])
+PATH_DTYPE = np.dtype([("ray", "<u4"), ("depth", "<u4"), ("modes", "<u4"), ("parent", "<u4"), ("attenuation", "<f8"),
+                       ("_pad", "<f8"), ("point", POINT_DTYPE)])
 COUNTER_DTYPE = np.dtype([("nodes_visited", "<u4"), ("tris_tested", "<u4")])
 PATCH_LEAF_DTYPE = np.dtype([("tu", "<f8", (3, 2)), ("patch", "<u4"), ("_pad", "<u4")])
 LIGHT_DTYPE = np.dtype([("position", "<f8", 3), ("color", "<f8", 3)])
@@ -125,6 +127,7 @@ _sig(lib.rtg_scene_create, C.c_int, _vp, C.POINTER(SceneDesc), C.POINTER(_vp))
 _sig(lib.rtg_scene_destroy, None, _vp)
 _sig(lib.rtg_render_primary, C.c_int, _vp, C.POINTER(View), C.c_uint32, C.c_uint32, Rect, _vp, _vp, _vp)
 _sig(lib.rtg_trace, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp, _vp)
+_sig(lib.rtg_trace_paths, C.c_int, _vp, _vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64))
 _sig(lib.rtg_shade_direct, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, _vp, _vp)
 _sig(lib.rtg_render_frame, C.c_int, _vp, C.POINTER(View), _vp, C.c_uint32, C.c_uint32, C.c_uint32, Rect,
      C.c_uint32, _vp, _vp, _vp)
@@ -595,6 +598,18 @@ class Scene:
         ctr = np.empty(n, dtype=COUNTER_DTYPE) if counters else None
         self.ctx._check(lib.rtg_trace(self._h, _ptr(rays6), n, _ptr(hits), _ptr(pts), _ptr(ctr)))
         return hits, pts, ctr
+
+    def trace_paths(self, rays6, max_depth=4, capacity=None):
+        """raytrace_all_specular per ray: PATH_DTYPE records in ray order, depth-first within a ray."""
+        rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
+        n = rays6.shape[0]
+        if capacity is None:
+            capacity = n * ((1 << max_depth) - 1)
+        out = np.zeros(capacity, dtype=PATH_DTYPE)
+        count = C.c_uint64()
+        self.ctx._check(lib.rtg_trace_paths(self._h, _ptr(rays6), n, max_depth, _ptr(out) if capacity else None, capacity,
+                                            C.byref(count)))
+        return out[:count.value]
 
     def trace_raw(self, rays_ptr, n, hits_ptr, points_ptr=None, counters_ptr=None):
         self.ctx._check(lib.rtg_trace(self._h, _ptr(rays_ptr), n, _ptr(hits_ptr), _ptr(points_ptr), _ptr(counters_ptr)))

@@ -69,6 +69,7 @@ _sig(lib.orc_scene_create, _vp, C.POINTER(rtg.SceneDesc))
 _sig(lib.orc_scene_destroy, None, _vp)
 _sig(lib.orc_render_primary, C.c_int, _vp, C.POINTER(rtg.View), C.c_uint32, C.c_uint32, rtg.Rect, _vp, _vp, _vp, C.c_int)
 _sig(lib.orc_trace, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_int)
+_sig(lib.orc_trace_paths, C.c_int, _vp, _vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64))
 _sig(lib.orc_shade_direct, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, _vp, _vp, C.c_int)
 _sig(lib.orc_render_frame, C.c_int, _vp, C.POINTER(rtg.View), _vp, C.c_uint32, C.c_uint32, C.c_uint32, rtg.Rect,
      C.c_uint32, _vp, _vp, _vp, C.c_int)
@@ -265,6 +266,14 @@ class OracleScene:
         lib.orc_render_primary(self._h, C.byref(view), width, height, rtg.Rect(x0, y0, w, h), hits.ctypes.data,
                                None if pts is None else pts.ctypes.data, None if ctr is None else ctr.ctypes.data, threads)
         return hits, pts, ctr
+
+    def trace_paths(self, rays6, max_depth=4):
+        rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
+        n = rays6.shape[0]
+        out = np.zeros(n * ((1 << max_depth) - 1), dtype=rtg.PATH_DTYPE)
+        count = C.c_uint64()
+        lib.orc_trace_paths(self._h, rays6.ctypes.data, n, max_depth, out.ctypes.data, out.shape[0], C.byref(count))
+        return out[:count.value]
 
     def trace(self, rays6, points=False, counters=False, threads=THREADS):
         rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)

@@ -510,3 +510,76 @@ def test_reciprocal_quotient_equals_ieee_division(gpu_ctx, family):
     bad, xb, db = gpu_ctx.selftest_division(1 << 28, family, seed=20261111 + family)
     x, d = struct.unpack("<d", struct.pack("<Q", xb))[0], struct.unpack("<d", struct.pack("<Q", db))[0]
     assert bad == 0, f"family {family}: {bad} quotients differ, e.g. x={x!r} d={d!r}"
+
+
+def _assert_paths_equal(g, c):
+    assert g.shape == c.shape
+    for f in ("ray", "depth", "modes", "parent"):
+        assert np.array_equal(g[f], c[f]), f
+    assert not scenes.float_bits_differ(g["attenuation"], c["attenuation"]).any()
+    gp, cp = g["point"], c["point"]
+    for f in ("manifold", "manifold_len", "material_slot"):
+        assert np.array_equal(gp[f], cp[f]), f
+    for f in ("time", "position", "inter_normal", "geo_normal", "manifold_point"):
+        assert not scenes.float_bits_differ(gp[f], cp[f]).any(), f
+
+
+@pytest.mark.parametrize("traversal", [0, 2])
+@pytest.mark.parametrize("max_depth", [1, 2, 4, 6])
+def test_specular_paths_of_a_ray_batch(gpu_ctx, traversal, max_depth):
+    """raytrace_all_specular for a batch (the photon pass's loop body, renderer.rs:119-138): every path record --
+    order, modes, parents, attenuation, point -- equals the recursion's, for rays leaving the two lights in all
+    directions and for camera rays."""
+    objs, meshes, lights, view = _glass_scene()
+    pair = scenes.Pair(gpu_ctx, objs, meshes)
+    gpu_ctx.set_option("traversal", traversal)
+    rng = np.random.default_rng(31)
+    d = rng.normal(size=(6000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    la = np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
+    origins = np.stack([np.asarray(la[i % len(la)]["position"], dtype=np.float64) for i in range(len(d))])
+    cam = rtg.bench_mesh_rays([-0.1, -0.1, 0.9, 0.1, 0.1, 1.0], 3000, seed=3)
+    cam[:, 3:] = (np.array([0.0, -0.15, -1.0]) + 0.35 * (cam[:, 3:])) / np.linalg.norm(
+        np.array([0.0, -0.15, -1.0]) + 0.35 * cam[:, 3:], axis=1, keepdims=True)
+    rays = np.concatenate([np.concatenate([origins, d], axis=1), cam])
+    try:
+        g = pair.gpu.trace_paths(rays, max_depth=max_depth)
+    finally:
+        gpu_ctx.set_option("traversal", 2)
+    c = pair.cpu.trace_paths(rays, max_depth=max_depth)
+    _assert_paths_equal(g, c)
+    assert (c["depth"] == 0).sum() > 4000
+    if max_depth >= 4:
+        assert (c["depth"] >= 2).sum() > 200 and (c["modes"] != 0).sum() > 200
+        # following parents recovers the surfaces a path bounced off (the reference's `manifolds`)
+        deep = np.flatnonzero(c["depth"] == 3)[:50]
+        for i in deep:
+            chain, at = [], g["parent"][i]
+            while at != rtg.RTG_NONE:
+                assert g["ray"][at] == g["ray"][i] and g["depth"][at] == g["depth"][i] - 1 - len(chain)
+                chain.append(at)
+                at = g["parent"][at]
+            assert len(chain) == 3
+
+
+def test_specular_paths_limits_and_plain_scenes(gpu_ctx):
+    objs, lights, view = scenes.default_objects(0)            # glass sphere over the checker plane, no mesh
+    pair = scenes.Pair(gpu_ctx, objs, {})
+    rays = rtg.bench_mesh_rays([-0.3, -0.3, 0.8, 0.3, 0.3, 1.0], 2000, seed=8)
+    rays[:, 3:] = (np.array([0.0, -0.2, -1.0]) + 0.3 * rays[:, 3:])
+    rays[:, 3:] /= np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+    g = pair.gpu.trace_paths(rays, max_depth=4)
+    c = pair.cpu.trace_paths(rays, max_depth=4)
+    _assert_paths_equal(g, c)
+    assert (c["depth"] > 0).sum() > 100
+    with pytest.raises(rtg.RtgError, match="room for"):
+        pair.gpu.trace_paths(rays, max_depth=4, capacity=len(c) - 1)
+    exact = pair.gpu.trace_paths(rays, max_depth=4, capacity=len(c))
+    _assert_paths_equal(exact, c)
+    with pytest.raises(rtg.RtgError, match="max_depth"):
+        pair.gpu.trace_paths(rays, max_depth=9)
+    assert len(pair.gpu.trace_paths(np.zeros((0, 6)), max_depth=4)) == 0
+    # rays that hit nothing give no paths
+    up = rays.copy()
+    up[:, 3:] = [0.0, 1.0, 0.0]
+    assert len(pair.gpu.trace_paths(up, max_depth=4)) == 0
