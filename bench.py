@@ -6,11 +6,15 @@ BVH traversal + ray/triangle intersection + closest hit -> 16-byte hit records) 
 terrain, inputs (scene, BVH) resident in HBM, outputs written to HBM.  With N > 1 every rank renders its own
 frame of the sequence (frame f -> rank f mod N, camera moved per frame; BVH replicated) and the hit buffers are
 gathered to rank 0 with RCCL inside the timed region, on a second stream so the gather of frame i overlaps the
-traversal of frame i+1 (two hit buffers per rank): weak scaling.
+traversal of frame i+1 (two hit buffers per rank): weak scaling.  Every GPU keeps `--inflight` frames in flight
+(default 2: two contexts with a stream each take the frames in turn, sharing one uploaded tree), because the tail of
+a persistent launch -- its last rays finishing on a half-empty GPU -- is best hidden under the next frame's start.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (k_trace_phased, the persistent traversal
 kernel behind rtg_render_primary) against HBM peak using ALGORITHMIC bytes (nodes visited x 64 B + triangles tested
-x 72 B + 16 B hit record per ray, counted by the kernel's counting build on the same frame); `roofline.traffic` is
+x 72 B + 16 B hit record per ray, counted by the kernel's counting build on the same frame) over the kernel's average
+launch duration from HIP events on the launching stream -- with two launches in flight a launch spans the time it
+shares the GPU with its neighbour, so `roofline.concurrent_launches` states how many overlap; `roofline.traffic` is
 the HBM traffic per launch from the rocprofv3 counter passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE),
 null when no committed pass matches the workload; `cpu_baseline` is the oracle (C++ restatement of the reference
 renderer, kind "port") timed on this host's cores on whole frames of the same sequence.
@@ -66,6 +70,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="ctx option key=value (e.g. tri_min=16)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--grid", type=str, default=None, help="NXxNY quads (default 1000x500)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="frames in flight per GPU: that many contexts (one stream each) take the frames in turn")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the gather path even with one rank (rehearses the multi-GPU step on a 1-GPU box)")
     args = ap.parse_args()
@@ -95,51 +101,67 @@ def main():
     tris = rtg.heightfield(nx, ny, SEED, LOCAL_SCALE)
     bvh = rtg.HostBvh(tris)                       # host-side BvhForest::subdivide + Bvh::new
     build_s = time.time() - t0
-    ctx = rtg.Context(local_rank)
-    if args.traversal >= 0:
-        ctx.set_option("traversal", args.traversal)
-    if use_dist:
-        # The persistent kernel fills every block slot of the GPU for the whole frame (128 VGPRs x 4 waves per
-        # SIMD), so a gather kernel on the second stream could only start when a frame drains.  Leaving 32 of the
-        # 1024 slots free lets RCCL's send/recv blocks run next to the traversal of the following frame.
-        ctx.set_option("max_blocks", 992)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        ctx.set_option(k, int(v))
-    stream = torch.cuda.Stream(dev)               # a real (non-null) stream: kernels, events and RCCL share it
+    # A persistent launch ends with a tail in which its last rays finish with the GPU half empty (a ray is a chain of
+    # ~90 dependent node fetches), so consecutive frames are given to `inflight` contexts in turn, each with its own
+    # stream: the next frame's blocks take over the block slots the previous frame's tail frees.  The contexts
+    # share one uploaded tree.
+    inflight = max(1, args.inflight)
+    ctxs, streams, scenes = [], [], []
+    mesh = None
+    for s_ in range(inflight):
+        c = rtg.Context(local_rank)
+        if args.traversal >= 0:
+            c.set_option("traversal", args.traversal)
+        if use_dist:
+            # The persistent kernel fills every block slot of the GPU for the whole frame (128 VGPRs x 4 waves per
+            # SIMD), so a gather kernel on the second stream could only start when a frame drains.  Leaving 32 of
+            # the 1024 slots free lets RCCL's send/recv blocks run next to the traversal of the following frame.
+            c.set_option("max_blocks", 992)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            c.set_option(k, int(v))
+        st = torch.cuda.Stream(dev)               # a real (non-null) stream: kernels, events and RCCL share it
+        c.set_stream(st.cuda_stream)
+        if mesh is None:
+            mesh = c.mesh(bvh)
+            obj = rtg.mesh_object(mesh, rtg.material((0.8, 0.7, 0.6)), rtg.transform(1.0 / LOCAL_SCALE))
+        ctxs.append(c)
+        streams.append(st)
+        scenes.append(c.scene([obj]))
+    ctx, stream, scene = ctxs[0], streams[0], scenes[0]
     torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
-    mesh = ctx.mesh(bvh)
-    obj = rtg.mesh_object(mesh, rtg.material((0.8, 0.7, 0.6)), rtg.transform(1.0 / LOCAL_SCALE))
-    scene = ctx.scene([obj])
 
     n_rays = WIDTH * HEIGHT
     tile = (0, 0, WIDTH, HEIGHT)
-    hits2 = [torch.empty(n_rays * 16, dtype=torch.uint8, device=dev) for _ in range(2 if use_dist else 1)]
-    hits = hits2[0]
+    n_buf = 2 if use_dist else 1
+    hits_of = [[torch.empty(n_rays * 16, dtype=torch.uint8, device=dev) for _ in range(n_buf)] for _ in range(inflight)]
+    hits = hits_of[0][0]
     sizes = [hits.numel()] * world
     if use_dist:
-        comm = torch.cuda.Stream(dev)                 # gathers run here, traversal on `stream`
-        recv = [[torch.empty_like(hits) for _ in range(world)] if rank == 0 else None for _ in range(2)]
-        rendered = [torch.cuda.Event() for _ in range(2)]
-        gathered = [torch.cuda.Event() for _ in range(2)]
+        comm = torch.cuda.Stream(dev)                 # gathers run here, traversal on the contexts' streams
+        recv = [[[torch.empty_like(hits) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+                for _ in range(inflight)]
+        rendered = [[torch.cuda.Event() for _ in range(2)] for _ in range(inflight)]
+        gathered = [[torch.cuda.Event() for _ in range(2)] for _ in range(inflight)]
 
     def step(i, ev=None):
         frame = i * world + rank
-        b = i & 1 if use_dist else 0
+        k = i % inflight                              # the context that takes this frame
+        b = (i // inflight) & 1 if use_dist else 0
+        st = streams[k]
         if use_dist:
-            stream.wait_event(gathered[b])            # hit buffer b is free once its previous gather has finished
+            st.wait_event(gathered[k][b])             # the hit buffer is free once its previous gather has finished
         if ev is not None:
-            ev[0].record(stream)
-        scene.render_primary_raw(frame_view(rtg, frame), WIDTH, HEIGHT, tile, hits2[b].data_ptr())
+            ev[0].record(st)
+        scenes[k].render_primary_raw(frame_view(rtg, frame), WIDTH, HEIGHT, tile, hits_of[k][b].data_ptr())
         if ev is not None:
-            ev[1].record(stream)
+            ev[1].record(st)
         if use_dist:
-            rendered[b].record(stream)
-            comm.wait_event(rendered[b])
+            rendered[k][b].record(st)
+            comm.wait_event(rendered[k][b])
             with torch.cuda.stream(comm):             # RCCL gather of the finished framebuffers to rank 0
-                shard.gather_to_root(hits2[b], sizes, dst=0, out=recv[b])
-                gathered[b].record(comm)
+                shard.gather_to_root(hits_of[k][b], sizes, dst=0, out=recv[k][b])
+                gathered[k][b].record(comm)
 
     for i in range(args.warmup):
         step(i)
@@ -209,11 +231,12 @@ def main():
                                    f"{WIDTH}x{HEIGHT} primary rays per step per GPU, closest-hit ids",
                        "traversal": "library default" if args.traversal < 0 else ["short-stack", "threaded", "phased-threaded"][args.traversal],
                        "parallelism": f"frames sharded over {world} GPU(s), BVH replicated"
-                                      + (", RCCL gather to rank 0 overlapped with the next frame" if use_dist else ""),
+                                      + (", RCCL gather to rank 0 overlapped with the next frame" if use_dist else "")
+                                      + f", {inflight} frame(s) in flight per GPU",
                        "host_bvh_build_s": round(build_s, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if traffic is None else round(traffic / 1e9, 4), "traffic_unit": "GB per launch",
-                         "kernel": kernel,
+                         "kernel": kernel, "concurrent_launches": inflight,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
                          "nodes_per_ray": round(float(nodes_per_ray), 2), "tris_per_ray": round(float(tris_per_ray), 2)},
             "cpu_baseline": cpu,

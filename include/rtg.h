@@ -280,7 +280,9 @@ int rtg_mesh_read_bvh(const rtg_mesh *mesh, rtg_bvh_node *nodes, rtg_tri *leaves
 /* `Bvh::bounds` (src/tree/bvh.rs:134-136): lo[3], hi[3] of the root. */
 int rtg_mesh_bounds(const rtg_mesh *mesh, double out_lo_hi[6]);
 
-/* Replaces `SceneObject::new` (src/render/scene_object.rs:13-17). */
+/* Replaces `SceneObject::new` (src/render/scene_object.rs:13-17).  The meshes may come from any context of the
+ * same GPU: contexts are how a caller keeps several frames in flight (one stream each), and they can share one
+ * uploaded tree. */
 int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out);
 void rtg_scene_destroy(rtg_scene *scene);
 

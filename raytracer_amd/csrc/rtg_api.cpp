@@ -878,7 +878,9 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
         case RTG_MESH:
         case RTG_PATCHES:
             if (!o.mesh) return fail(ctx, RTG_E_INVALID, "object %u: mesh handle is null", i);
-            if (o.mesh->ctx != ctx) return fail(ctx, RTG_E_INVALID, "object %u: mesh belongs to another context", i);
+            // a mesh is immutable once created, so contexts of one GPU may share it (several frames in flight)
+            if (o.mesh->ctx != ctx && o.mesh->ctx->device != ctx->device)
+                return fail(ctx, RTG_E_INVALID, "object %u: mesh belongs to a context on another GPU", i);
             if ((o.kind == RTG_PATCHES) != o.mesh->is_patches)
                 return fail(ctx, RTG_E_INVALID, "object %u: kind %d does not match the mesh handle (%s)", i, o.kind,
                             o.mesh->is_patches ? "patch set" : "triangle mesh");

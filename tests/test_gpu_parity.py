@@ -583,3 +583,41 @@ def test_specular_paths_limits_and_plain_scenes(gpu_ctx):
     up = rays.copy()
     up[:, 3:] = [0.0, 1.0, 0.0]
     assert len(pair.gpu.trace_paths(up, max_depth=4)) == 0
+
+
+def test_contexts_of_one_gpu_share_a_mesh_with_frames_in_flight(gpu_ctx):
+    """Two contexts (a stream each) render alternate frames from one uploaded tree; every frame equals the frame a
+    single context renders, and the oracle's for the first."""
+    import torch
+    tris, xform = scenes.terrain(60, 50, seed=12)
+    bvh = rtg.HostBvh(tris)
+    mesh = gpu_ctx.mesh(bvh)
+    obj = rtg.mesh_object(mesh, rtg.material((0.5, 0.5, 0.5)), xform)
+    other = rtg.Context(0)
+    ctxs = [gpu_ctx, other]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for c, st in zip(ctxs, streams):
+        c.set_stream(st.cuda_stream)
+    try:
+        sc = [c.scene([obj]) for c in ctxs]
+        w, h, n_frames = 320, 200, 12
+        views = [rtg.make_view(orig=(0.02 * f, 0.01 * f, 1.0)) for f in range(n_frames)]
+        out = [torch.empty(w * h * 16, dtype=torch.uint8, device="cuda") for _ in range(n_frames)]
+        torch.cuda.synchronize()
+        for f in range(n_frames):
+            sc[f & 1].render_primary_raw(views[f], w, h, (0, 0, w, h), out[f].data_ptr())
+        torch.cuda.synchronize()
+        for f in range(n_frames):
+            alone, _, _ = sc[0].render_primary(views[f], w, h)
+            got = np.frombuffer(out[f].cpu().numpy().tobytes(), dtype=rtg.HIT_DTYPE)
+            _assert_hits_equal(got, alone)
+        obvh = orc.OracleBvh(flat=bvh.view)
+        oscene = orc.OracleScene([orc.oracle_object(obj, obvh)])
+        c_hits, _, _ = oscene.render_primary(views[0], w, h)
+        _assert_hits_equal(np.frombuffer(out[0].cpu().numpy().tobytes(), dtype=rtg.HIT_DTYPE), c_hits)
+        assert (c_hits["leaf"] != rtg.RTG_NONE).mean() > 0.3
+        for s_ in sc:
+            s_.close()
+    finally:
+        gpu_ctx.set_stream(None)
+        other.close()
