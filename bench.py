@@ -165,6 +165,15 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    # The kernel's duration for the roofline: HIP events that the launch itself fills with its execution window
+    # (the dispatch's own begin and end timestamps -- what rocprofv3 reports per dispatch).  Events recorded around the call
+    # would also count the time a launch waits in its stream's queue while the previous frame still owns the GPU.
+    timed_kernels = args.traversal in (-1, 2)
+    if timed_kernels:
+        torch.cuda.synchronize(dev)
+        for c in ctxs:
+            c.set_option("time_kernels", 2)
+            c.kernel_time()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if use_dist:
         dist.barrier()
@@ -181,6 +190,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    if timed_kernels:
+        windows = [c.kernel_time() for c in ctxs]
+        for c in ctxs:
+            c.set_option("time_kernels", 1)
+        assert sum(n for _, n in windows) == args.steps
+        kernel_ms = sum(ms for ms, _ in windows) / args.steps
 
     if rank == 0:
         # algorithmic bytes of one launch, from the kernel's own counting build on frame 0

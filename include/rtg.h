@@ -229,8 +229,14 @@ int rtg_ctx_synchronize(rtg_ctx *ctx);
  *   "patch_tri_min"                     lanes waiting for a patch leaf's Newton solve before one runs
  *   "max_blocks"                        persistent grid size of traversal 2
  *   "pretest" 2 = on (default), 1 = off: single-precision box pre-test of traversal 2
- *   "stats" 2 = tally steps per phase in traversal 2 (diagnostics), 1 = off */
+ *   "stats" 2 = tally steps per phase in traversal 2 (diagnostics), 1 = off
+ *   "time_kernels" 2 = record each persistent-kernel launch's execution window (rtg_ctx_kernel_time), 1 = off */
 int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value);
+/* With option "time_kernels" = 2 every persistent-kernel launch behind rtg_render_primary / rtg_trace records its
+ * execution window (the dispatch's own begin and end timestamps: the duration a profiler reports for the kernel,
+ * also while launches of other contexts share the GPU).  This call waits for the context's stream, returns the summed
+ * windows and the number of launches since the previous call, and starts over. */
+int rtg_ctx_kernel_time(rtg_ctx *ctx, double *total_ms, uint64_t *launches);
 /* Diagnostics for traversal 2 after a launch with "stats" on: loop iterations,
  * node steps, node lanes, tri steps, tri lanes, obj steps, obj lanes, refills,
  * waves (no reference counterpart). */

@@ -39,6 +39,10 @@ struct rtg_ctx {
     PhasedTuning tune;
     std::string err;
     std::map<std::string, DeviceBuffer> scratch;
+    // option "time_kernels": execution windows of the persistent kernel launches behind rtg_render_primary and
+    // rtg_trace, summed by rtg_ctx_kernel_time
+    bool time_kernels = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, idle_events;
 };
 
 struct rtg_mesh {
@@ -105,6 +109,24 @@ bool is_device_pointer(const void *p) {
 }
 
 int scratch_get(rtg_ctx *ctx, const char *name, size_t bytes, void **out);
+
+// Tuning of one timed launch: with "time_kernels" on, an event pair for the launch's execution window.
+int tuning_for_launch(rtg_ctx *ctx, PhasedTuning &t) {
+    t = ctx->tune;
+    if (!ctx->time_kernels) return RTG_OK;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (!ctx->idle_events.empty()) {
+        ev = ctx->idle_events.back();
+        ctx->idle_events.pop_back();
+    } else {
+        HIP_TRY(ctx, hipEventCreate(&ev.first));
+        HIP_TRY(ctx, hipEventCreate(&ev.second));
+    }
+    ctx->timed.push_back(ev);
+    t.time_start = ev.first;
+    t.time_stop = ev.second;
+    return RTG_OK;
+}
 
 // Scratch of one persistent launch with `n_out` output slots on `scene`.
 int phased_scratch(rtg_ctx *ctx, const DevScene &ds, uint64_t n_out, PhasedScratch &ps) {
@@ -374,6 +396,11 @@ void rtg_ctx_destroy(rtg_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->scratch)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    for (auto *list : {&ctx->timed, &ctx->idle_events})
+        for (auto &ev : *list) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -424,11 +451,33 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) {
         ctx->tune.pretest = value > 1 ? 1u : 0u;   // 2 = on, 1 = off
         return RTG_OK;
     }
+    if (std::strcmp(key, "time_kernels") == 0) {
+        ctx->time_kernels = value > 1;           // 2 = on, 1 = off
+        return RTG_OK;
+    }
     if (std::strcmp(key, "stats") == 0) {
         ctx->tune.stats = value > 1 ? 1u : 0u;   // 2 = on, 1 = off (0 is rejected above as out of range)
         return RTG_OK;
     }
     return fail(ctx, RTG_E_INVALID, "unknown option '%s'", key);
+}
+
+int rtg_ctx_kernel_time(rtg_ctx *ctx, double *total_ms, uint64_t *launches) {
+    if (!ctx || !total_ms || !launches) return fail(ctx, RTG_E_INVALID, "null argument");
+    *total_ms = 0.0;
+    *launches = 0;
+    int rc = bind_device(ctx);
+    if (rc != RTG_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &ev : ctx->timed) {
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
+        *total_ms += (double)ms;
+        *launches += 1;
+    }
+    ctx->idle_events.insert(ctx->idle_events.end(), ctx->timed.begin(), ctx->timed.end());
+    ctx->timed.clear();
+    return RTG_OK;
 }
 
 int rtg_ctx_debug_stats(rtg_ctx *ctx, uint32_t out[16]) {
@@ -969,7 +1018,9 @@ int rtg_render_primary(rtg_scene *scene, const rtg_view *view, uint32_t width, u
         PhasedScratch ps;
         if ((rc = phased_scratch(ctx, ds, n, ps)) != RTG_OK) return rc;
         if (op.dev && !hits && (rc = scratch_get(ctx, "points_hits", n * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
-        HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, ps, ctx->tune,
+        PhasedTuning tune;
+        if ((rc = tuning_for_launch(ctx, tune)) != RTG_OK) return rc;
+        HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, ps, tune,
                                                   (rtg_hit *)hits, (rtg_ray_counters *)oc.dev));
         if (op.dev)
             HIP_TRY(ctx, launch_points_primary(ctx->stream, ds, *view, width, height, tile, (const rtg_hit *)hits,
@@ -1010,7 +1061,9 @@ int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *o
         PhasedScratch ps;
         if ((rc = phased_scratch(ctx, ds, n_rays, ps)) != RTG_OK) return rc;
         if (op.dev && !hits && (rc = scratch_get(ctx, "points_hits", n_rays * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
-        HIP_TRY(ctx, launch_trace_phased(ctx->stream, ds, (const double *)d_rays, n_rays, ps, ctx->tune,
+        PhasedTuning tune;
+        if ((rc = tuning_for_launch(ctx, tune)) != RTG_OK) return rc;
+        HIP_TRY(ctx, launch_trace_phased(ctx->stream, ds, (const double *)d_rays, n_rays, ps, tune,
                                          (rtg_hit *)hits, (rtg_ray_counters *)oc.dev));
         if (op.dev)
             HIP_TRY(ctx, launch_points_batch(ctx->stream, ds, (const double *)d_rays, n_rays, (const rtg_hit *)hits,

@@ -28,6 +28,9 @@ struct PhasedTuning {
     uint32_t max_blocks = 1024;
     uint32_t pretest = 1;        // single-precision box pre-test with exact fallback
     uint32_t stats = 0;          // diagnostics build: tally steps and lanes per phase
+    // when set, the persistent kernel's launch records its execution window (the dispatch's own begin and end
+    // timestamps, what a profiler reports as the kernel's duration) in these events
+    hipEvent_t time_start = nullptr, time_stop = nullptr;
 };
 // Device scratch of one persistent launch: the work counters (8 * 32 + 16 u32) and, for scenes that mix meshes
 // with spheres or planes, one rtg_hit per output slot for the closest sphere / plane hit.

@@ -38,6 +38,8 @@
 // nothing over/underflows on the way.  Rays and meshes whose magnitudes could
 // do that (see fast_div_ray_ok / the host's mesh check) take the plain
 // division path; results are identical either way.
+#include <hip/hip_ext.h>
+
 #include "rtg_device.hpp"
 #include "rtg_launch.hpp"
 
@@ -1007,8 +1009,8 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     const size_t cold_bytes = (size_t)(keep ? 9 : 3) * kBlock * sizeof(double);
     dim3 g(grid), b(kBlock);
 #define RTG_L(C, X, P, K, S)                                                                                      \
-    hipLaunchKernelGGL((k_trace_phased<Source, C, X, P, K, S>), g, b, cold_bytes, stream, s, src, n_items,       \
-                       work_counters, prm, out_hits, out_counters, prim_best)
+    hipExtLaunchKernelGGL((k_trace_phased<Source, C, X, P, K, S>), g, b, cold_bytes, stream, tune.time_start,    \
+                          tune.time_stop, 0, s, src, n_items, work_counters, prm, out_hits, out_counters, prim_best)
 #define RTG_L_PRE(C, X, K, S) \
     do {                      \
         if (pre)              \

@@ -111,6 +111,7 @@ _sig(lib.rtg_ctx_set_stream, C.c_int, _vp, _vp)
 _sig(lib.rtg_ctx_get_stream, _vp, _vp)
 _sig(lib.rtg_ctx_synchronize, C.c_int, _vp)
 _sig(lib.rtg_ctx_set_option, C.c_int, _vp, C.c_char_p, C.c_int64)
+_sig(lib.rtg_ctx_kernel_time, C.c_int, _vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64))
 _sig(lib.rtg_ctx_debug_stats, C.c_int, _vp, C.POINTER(C.c_uint32))
 _sig(lib.rtg_selftest_division, C.c_int, _vp, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64))
 _sig(lib.rtg_transform_from_forward, C.c_int, C.POINTER(C.c_double), C.POINTER(Transform))
@@ -402,6 +403,12 @@ class Context:
         out = (C.c_uint64 * 3)()
         self._check(lib.rtg_selftest_division(self._h, seed, n_pairs, family, out))
         return int(out[0]), int(out[1]), int(out[2])
+
+    def kernel_time(self):
+        """(summed execution windows in ms, launches) of the timed persistent-kernel launches since the last call."""
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(lib.rtg_ctx_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def debug_stats(self):
         out = (C.c_uint32 * 16)()

@@ -621,3 +621,23 @@ def test_contexts_of_one_gpu_share_a_mesh_with_frames_in_flight(gpu_ctx):
     finally:
         gpu_ctx.set_stream(None)
         other.close()
+
+
+def test_kernel_time_reports_every_timed_launch(gpu_ctx):
+    tris, xform = scenes.terrain(40, 40, seed=3)
+    pair = scenes.Pair(gpu_ctx, scenes.mesh_scene_objects(xform, with_default=False)[0], {0: rtg.HostBvh(tris)})
+    view = rtg.make_view()
+    assert gpu_ctx.kernel_time() == (0.0, 0)                  # nothing is timed unless asked for
+    gpu_ctx.set_option("time_kernels", 2)
+    try:
+        for _ in range(5):
+            pair.gpu.render_primary(view, 256, 192)
+        rays = rtg.bench_mesh_rays([-1, -1, -1, 1, 1, 1], 5000, seed=2)
+        pair.gpu.trace(rays)
+        ms, n = gpu_ctx.kernel_time()
+        assert n == 6 and 0.0 < ms < 600.0
+        assert gpu_ctx.kernel_time() == (0.0, 0)              # the query starts over
+    finally:
+        gpu_ctx.set_option("time_kernels", 1)
+    pair.gpu.render_primary(view, 64, 64)
+    assert gpu_ctx.kernel_time() == (0.0, 0)
