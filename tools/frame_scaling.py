@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""Kernel time of the default primary-ray path against the frame size (same camera, growing resolution) and per
+horizontal band of the 1920x1080 frame: shows the fixed cost of a persistent launch -- the chain of dependent node
+fetches of its last rays -- next to the per-ray cost.
+
+    python tools/frame_scaling.py
+"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
