@@ -230,6 +230,8 @@ int rtg_ctx_synchronize(rtg_ctx *ctx);
  *   "max_blocks"                        persistent grid size of traversal 2
  *   "pretest" 2 = on (default), 1 = off: single-precision box pre-test of traversal 2
  *   "stats" 2 = tally steps per phase in traversal 2 (diagnostics), 1 = off
+ *   "frame_bands" 2 = rtg_render_frame issues an opaque scene's frame as two row bands on two streams, so one
+ *                     band's launches run while the other's drain (default), 1 = one band
  *   "time_kernels" 2 = record each persistent-kernel launch's execution window (rtg_ctx_kernel_time), 1 = off */
 int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value);
 /* With option "time_kernels" = 2 every persistent-kernel launch behind rtg_render_primary / rtg_trace records its

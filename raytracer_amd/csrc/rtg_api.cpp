@@ -43,6 +43,11 @@ struct rtg_ctx {
     // rtg_trace, summed by rtg_ctx_kernel_time
     bool time_kernels = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, idle_events;
+    // rtg_render_frame renders a frame of an opaque scene as two row bands on two streams (option "frame_bands"):
+    // `side` is an internal context (own stream and scratch) for the second band, joined back by events
+    uint32_t frame_bands = 2;
+    rtg_ctx *side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 struct rtg_mesh {
@@ -396,6 +401,9 @@ void rtg_ctx_destroy(rtg_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->scratch)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    if (ctx->side) rtg_ctx_destroy(ctx->side);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (auto *list : {&ctx->timed, &ctx->idle_events})
         for (auto &ev : *list) {
             (void)hipEventDestroy(ev.first);
@@ -449,6 +457,10 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) {
     }
     if (std::strcmp(key, "pretest") == 0) {
         ctx->tune.pretest = value > 1 ? 1u : 0u;   // 2 = on, 1 = off
+        return RTG_OK;
+    }
+    if (std::strcmp(key, "frame_bands") == 0) {
+        ctx->frame_bands = value >= 2 ? 2u : 1u;
         return RTG_OK;
     }
     if (std::strcmp(key, "time_kernels") == 0) {
@@ -1376,32 +1388,73 @@ int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *li
         // persistent kernel's building blocks (primary hit ids, point records, shadow rays, resolve); the pixels
         // whose primary hit has a dielectric material -- the only ones with a path tree -- are then redone by the
         // fused kernel.
-        void *pts = nullptr;
-        PhasedScratch ps;
-        if ((rc = phased_scratch(ctx, ds, n, ps)) != RTG_OK) return rc;
-        if ((rc = scratch_get(ctx, "frame_points", n * sizeof(rtg_point), &pts)) != RTG_OK) return rc;
-        void *hits = oh.dev;
-        if (!hits && (rc = scratch_get(ctx, "points_hits", n * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
-        HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, ps, ctx->tune,
-                                                  (rtg_hit *)hits, nullptr));
-        if (orgb.dev || o8.dev) {
-            const bool spec = scene->any_dielectric && max_depth > 1;
-            void *frame_rgb = orgb.dev;          // the path-tree re-sum needs the linear radiance of level 0
-            if (spec && !frame_rgb && (rc = scratch_get(ctx, "frame_rgb", n * 3 * sizeof(double), &frame_rgb)) != RTG_OK)
-                return rc;
-            HIP_TRY(ctx, launch_points_primary(ctx->stream, ds, *view, width, height, tile, (const rtg_hit *)hits,
-                                               (rtg_point *)pts));
-            bool done = true;
-            if ((rc = frame_wavefront(ctx, ds, *view, width, height, tile, (const rtg_light *)d_lights, n_lights,
-                                      (const rtg_point *)pts, n, max_depth, spec, (double *)frame_rgb, (double *)orgb.dev,
-                                      (uint8_t *)o8.dev, &done)) != RTG_OK)
-                return rc;
-            if (spec) {
-                if (!done)      // slot table over budget: the fused kernel redoes the refracting pixels
-                    HIP_TRY(ctx, launch_render_frame(ctx->stream, ds, *view, (const rtg_light *)d_lights, n_lights, width,
-                                                     height, tile, max_depth, (double *)orgb.dev, (uint8_t *)o8.dev,
-                                                     nullptr, (const rtg_point *)pts));
+        const bool spec = scene->any_dielectric && max_depth > 1;
+        // An opaque scene's frame has no host read-backs, so it is issued as two row bands on two streams: a
+        // persistent launch ends with a tail (its last rays finish on a half-empty GPU) and the other band's
+        // launches fill it.  The second band runs on an internal context (own stream and scratch) that is forked
+        // from and joined back into the context's stream by events.
+        uint32_t n_bands = (!spec && ctx->frame_bands >= 2 && tile.h >= 128) ? 2u : 1u;
+        rtg_ctx *lanes[2] = {ctx, nullptr};
+        if (n_bands == 2) {
+            if (!ctx->side) {
+                if (rtg_ctx_create(ctx->device, &ctx->side) != RTG_OK)
+                    return fail(ctx, RTG_E_HIP, "rtg_render_frame: internal context: %s", g_create_error.c_str());
+                HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
             }
+            lanes[1] = ctx->side;
+            lanes[1]->traversal = ctx->traversal;
+            lanes[1]->tune = ctx->tune;
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));        // inputs uploaded, earlier calls ordered
+            HIP_TRY(ctx, hipStreamWaitEvent(lanes[1]->stream, ctx->ev_fork, 0));
+        }
+        const uint32_t h0 = n_bands == 2 ? ((tile.h / 2 + 7u) / 8u) * 8u : tile.h;
+        for (uint32_t band = 0; band < n_bands; band++) {
+            rtg_ctx *lane = lanes[band];
+            rtg_rect bt = tile;
+            bt.y0 = tile.y0 + (band ? h0 : 0u);
+            bt.h = band ? tile.h - h0 : h0;
+            const uint64_t first = band ? (uint64_t)h0 * tile.w : 0, bn = (uint64_t)bt.w * bt.h;
+            auto run = [&]() -> int {
+                int r;
+                void *pts = nullptr;
+                PhasedScratch ps;
+                if ((r = phased_scratch(lane, ds, bn, ps)) != RTG_OK) return r;
+                if ((r = scratch_get(lane, "frame_points", bn * sizeof(rtg_point), &pts)) != RTG_OK) return r;
+                void *hits = oh.dev ? (void *)((rtg_hit *)oh.dev + first) : nullptr;
+                if (!hits && (r = scratch_get(lane, "points_hits", bn * sizeof(rtg_hit), &hits)) != RTG_OK) return r;
+                HIP_TRY(lane, launch_render_primary_phased(lane->stream, ds, *view, width, height, bt, ps, lane->tune,
+                                                           (rtg_hit *)hits, nullptr));
+                if (orgb.dev || o8.dev) {
+                    double *rgb_out = orgb.dev ? (double *)orgb.dev + first * 3 : nullptr;
+                    uint8_t *c8_out = o8.dev ? (uint8_t *)o8.dev + first * 4 : nullptr;
+                    void *frame_rgb = rgb_out;   // the path-tree re-sum needs the linear radiance of level 0
+                    if (spec && !frame_rgb && (r = scratch_get(lane, "frame_rgb", bn * 3 * sizeof(double), &frame_rgb)) != RTG_OK)
+                        return r;
+                    HIP_TRY(lane, launch_points_primary(lane->stream, ds, *view, width, height, bt, (const rtg_hit *)hits,
+                                                        (rtg_point *)pts));
+                    bool done = true;
+                    if ((r = frame_wavefront(lane, ds, *view, width, height, bt, (const rtg_light *)d_lights, n_lights,
+                                             (const rtg_point *)pts, bn, max_depth, spec, (double *)frame_rgb, rgb_out,
+                                             c8_out, &done)) != RTG_OK)
+                        return r;
+                    if (spec && !done)      // slot table over budget: the fused kernel redoes the refracting pixels
+                        HIP_TRY(lane, launch_render_frame(lane->stream, ds, *view, (const rtg_light *)d_lights, n_lights,
+                                                          width, height, bt, max_depth, rgb_out, c8_out, nullptr,
+                                                          (const rtg_point *)pts));
+                }
+                return RTG_OK;
+            };
+            rc = run();
+            if (rc != RTG_OK) {
+                if (lane != ctx) ctx->err = lane->err;
+                if (n_bands == 2) (void)hipStreamSynchronize(lanes[1]->stream);
+                return rc;
+            }
+        }
+        if (n_bands == 2) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, lanes[1]->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         }
     } else {
         HIP_TRY(ctx, launch_render_frame(ctx->stream, ds, *view, (const rtg_light *)d_lights, n_lights, width, height,

@@ -641,3 +641,40 @@ def test_kernel_time_reports_every_timed_launch(gpu_ctx):
         gpu_ctx.set_option("time_kernels", 1)
     pair.gpu.render_primary(view, 64, 64)
     assert gpu_ctx.kernel_time() == (0.0, 0)
+
+
+def test_frame_in_two_row_bands_equals_one_band(gpu_ctx):
+    """An opaque scene's frame is issued as two row bands on two streams; outputs (device and host buffers, full
+    frame and ragged tile) equal the one-band frame and the oracle's."""
+    import torch
+    tris, xform = scenes.terrain(50, 50, seed=21)
+    objs, lights, view = scenes.mesh_scene_objects(xform, with_default=True)
+    objs[0] = rtg.sphere_object((0.0, -0.2, 0.0), 0.2, rtg.material((0.3, 0.2, 0.6)))      # opaque sphere
+    pair = scenes.Pair(gpu_ctx, objs, {2: rtg.HostBvh(tris, vertex_normals=scenes.vertex_normals_for(tris))})
+    w, h = 352, 300
+    la = np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
+    try:
+        for tile in (None, (5, 3, 301, 277)):
+            gpu_ctx.set_option("frame_bands", 1)
+            one = pair.gpu.render_frame(view, lights, w, h, tile=tile, max_depth=4)
+            gpu_ctx.set_option("frame_bands", 2)
+            two = pair.gpu.render_frame(view, lights, w, h, tile=tile, max_depth=4)
+            for a, b in zip(one, two):
+                assert a.tobytes() == b.tobytes()
+            c_rgb, c_c8, c_hits = pair.cpu.render_frame(view, lights, w, h, tile=tile, max_depth=4)
+            _assert_hits_equal(two[2], c_hits)
+            assert not scenes.float_bits_differ(two[0], c_rgb).any()
+            assert np.abs(two[1].astype(int) - c_c8.astype(int)).max() <= 1
+        # device buffers, several frames back to back on the context's stream
+        n = w * h
+        d_rgb = torch.empty(n * 3, dtype=torch.float64, device="cuda")
+        d_c8 = torch.empty(n * 4, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(3):
+            pair.gpu.render_frame_raw(view, la, len(la), w, h, (0, 0, w, h), 4, d_rgb.data_ptr(), d_c8.data_ptr(), None)
+        gpu_ctx.synchronize()
+        full = pair.gpu.render_frame(view, lights, w, h, max_depth=4)
+        assert d_rgb.cpu().numpy().tobytes() == full[0].tobytes()
+        assert d_c8.cpu().numpy().tobytes() == full[1].tobytes()
+    finally:
+        gpu_ctx.set_option("frame_bands", 2)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times the fused frame kernel (primary + direct light + specular tree + PQ) on the bench mesh (GPU box)."""
+"""Times rtg_render_frame (primary + direct light + specular tree + PQ) on the bench mesh (GPU box).
+    python tools/frame_time.py [W H [traversal [option=value ...]]]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -15,6 +16,9 @@ bvh = rtg.HostBvh(tris)
 ctx = rtg.Context(0)
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); ctx.set_stream(stream.cuda_stream)
 ctx.set_option("traversal", TRAVERSAL)
+for kv in sys.argv[4:]:
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
 mesh = ctx.mesh(bvh)
 _, lights, view = scenes.default_objects(0)
 mesh_obj = rtg.mesh_object(mesh, rtg.material((0.8, 0.7, 0.6)), rtg.transform(1.0 / bench.LOCAL_SCALE))
