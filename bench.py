@@ -85,7 +85,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
     torch.cuda.set_device(local_rank)
+    json_out = sys.stdout
     if use_dist:
+        # RCCL prints a version banner on stdout when it creates a communicator: the one JSON line goes to the real
+        # stdout, everything else the process writes there is sent to stderr
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -256,7 +262,7 @@ def main():
                          "nodes_per_ray": round(float(nodes_per_ray), 2), "tris_per_ray": round(float(tris_per_ray), 2)},
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
