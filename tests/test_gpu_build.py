@@ -180,3 +180,35 @@ def test_patch_set_built_on_the_device(gpu_ctx):
     for a, b in zip(*out):
         assert a.tobytes() == b.tobytes()
     assert (out[0][0]["leaf"] != 0xFFFFFFFF).mean() > 0.2
+
+
+def test_build_entry_points_reject_bad_arguments(gpu_ctx):
+    import ctypes as C
+    lib = rtg.lib
+    h = C.c_void_p()
+    tris = _soup(10, 1, 0.0)
+    assert lib.rtg_mesh_build(gpu_ctx._h, None, 10, None, C.byref(h)) == -1          # RTG_E_INVALID: null triangles
+    assert b"null argument" in lib.rtg_last_error(gpu_ctx._h)
+    assert lib.rtg_mesh_build(gpu_ctx._h, rtg._ptr(tris), 10, None, None) == -1
+    assert lib.rtg_mesh_build(gpu_ctx._h, rtg._ptr(tris), (1 << 30) + 1, None, C.byref(h)) != 0
+    assert b"2^30" in lib.rtg_last_error(gpu_ctx._h)
+    # patch sets: leaf records must name existing patches
+    patches = rtg.patch_terrain(3, 3, seed=1, scale=1.0)
+    facets, info = rtg.patches_tessellate(patches, 2)
+    info = np.ascontiguousarray(info).copy()
+    info["patch"][5] = len(patches)
+    ps = rtg.PatchSet()
+    ps.patches = patches.ctypes.data
+    ps.n_patches = patches.shape[0]
+    ps.leaf_info = info.ctypes.data
+    ps.newton_steps = 5
+    assert lib.rtg_mesh_build_patches(gpu_ctx._h, rtg._ptr(facets), facets.shape[0], C.byref(ps), C.byref(h)) == -1
+    assert b"names patch" in lib.rtg_last_error(gpu_ctx._h)
+    ps.newton_steps = 65
+    info["patch"][5] = 0
+    assert lib.rtg_mesh_build_patches(gpu_ctx._h, rtg._ptr(facets), facets.shape[0], C.byref(ps), C.byref(h)) != 0
+    # read-back with every output optional
+    mesh = gpu_ctx.build_mesh(tris)
+    assert lib.rtg_mesh_read_bvh(mesh._h, None, None, None) == 0
+    assert lib.rtg_mesh_sizes(mesh._h, None, None, None, None) == 0
+    assert lib.rtg_mesh_sizes(None, None, None, None, None) == -1
