@@ -120,6 +120,7 @@ uint64_t rth_to_hdr(const double *rgb, uint32_t width, uint32_t height, uint8_t 
     if (out && cap >= b.size()) std::memcpy(out, b.data(), b.size());
     return b.size();
 }
+void rth_fibonacci_sphere(uint64_t count, uint64_t seed, double *dirs3) { rt::fibonacci_sphere(count, seed, dirs3); }
 uint64_t rth_images_tar(const double *rgb, uint32_t width, uint32_t height, double seconds, uint8_t *out, uint64_t cap) {
     std::map<std::string, std::vector<uint8_t>> images;                    // Renderer::images (renderer.rs:379-385)
     const size_t n = (size_t)width * height * 3;

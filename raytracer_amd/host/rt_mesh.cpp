@@ -90,6 +90,31 @@ void bench_mesh_rays(const double b[6], uint64_t n, uint64_t seed, double *rays6
     }
 }
 
+// Sphere::fibonacci_sphere + ZenithY::into_normal (geo/sphere.rs:27-32,48-80): direction i of `count` sits at
+// zenith (phi * (i + u)) mod 2 pi and height -1 + dydi * (i + u) + dydj * v, with u, v in [0, 1) drawn per
+// direction.  The reference draws them from an entropy-seeded generator (renderer.rs:112), so no two of its runs
+// agree; here they come from the seeded SplitMix64 stream used by the other generators.
+void fibonacci_sphere(uint64_t count, uint64_t seed, double *dirs3) {
+    const double pi = 3.14159265358979323846264338327950288;
+    const double n = (double)count;
+    const double phi = pi * (3.0 - std::sqrt(5.0));
+    const double d = 2.0 * pi / phi;
+    const double dydi = 2.0 / (n + d);
+    const double dydj = dydi * d;
+    uint64_t s = seed;
+    auto uni = [&s]() { return (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0); };
+    for (uint64_t k = 0; k < count; k++) {
+        double i = (double)k + uni();
+        double j = uni();
+        double zenith = std::fmod(phi * i, 2.0 * pi);
+        double y = -1.0 + dydi * i + dydj * j;
+        double radius = std::sqrt(1.0 - y * y);
+        dirs3[k * 3 + 0] = std::cos(zenith) * radius;
+        dirs3[k * 3 + 1] = y;
+        dirs3[k * 3 + 2] = std::sin(zenith) * radius;
+    }
+}
+
 uint64_t ray_sort_key(const double b[6], const double *ray6) {
     uint64_t key = 0;
     uint32_t q[3];

@@ -23,6 +23,10 @@ void heightfield(uint32_t nx, uint32_t ny, uint64_t seed, double scale, rtg_tri 
 // then normalised.  Rays are 6 doubles: orig.xyz, dir.xyz.
 void bench_mesh_rays(const double lo_hi[6], uint64_t n, uint64_t seed, double *rays6);
 
+// Photon directions: Sphere::fibonacci_sphere + ZenithY::into_normal (src/geo/sphere.rs:27-32,48-80), `count`
+// unit vectors (3 doubles each) with the per-direction jitter drawn from a seeded stream.
+void fibonacci_sphere(uint64_t count, uint64_t seed, double *dirs3);
+
 // 30-bit Morton code of the origin inside lo_hi, with the direction octant in
 // the three top bits: the sort key used to make a ray batch wave-coherent.
 uint64_t ray_sort_key(const double lo_hi[6], const double *ray6);

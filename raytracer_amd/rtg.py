@@ -140,6 +140,7 @@ _sig(host.rth_bvh_view, None, _vp, C.POINTER(Bvh))
 _sig(host.rth_bvh_leaf_source, C.POINTER(C.c_uint32), _vp)
 _sig(host.rth_bvh_depth, C.c_uint32, _vp)
 _sig(host.rth_heightfield, None, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, _vp)
+_sig(host.rth_fibonacci_sphere, None, C.c_uint64, C.c_uint64, _vp)
 _sig(host.rth_bench_mesh_rays, None, C.POINTER(C.c_double), C.c_uint64, C.c_uint64, _vp)
 _sig(host.rth_sort_rays, None, C.POINTER(C.c_double), _vp, C.c_uint64, _vp, _vp)
 _sig(host.rth_trispline_from_normal_hermite, None, _vp, _vp)
@@ -230,6 +231,13 @@ class HostPatchMesh:
         ps.newton_steps = self.newton_steps
         ps._keep = self
         return ps
+
+
+def fibonacci_sphere(count, seed=1):
+    """Sphere::fibonacci_sphere + into_normal: (count, 3) unit directions for the photon pass."""
+    out = np.empty((count, 3), dtype=np.float64)
+    host.rth_fibonacci_sphere(count, seed, _ptr(out))
+    return out
 
 
 def bench_mesh_rays(lo_hi, n, seed=10212233):

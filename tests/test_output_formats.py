@@ -46,3 +46,23 @@ def test_images_tar_holds_the_three_images():
         assert np.all(np.abs(perf - want) <= want / 128.0)
         pq = _decode_hdr(tar.extractfile(members["image.pq.hdr"]).read())
         assert np.all((pq >= 0.0) & (pq <= 1.0))
+
+
+def test_fibonacci_sphere_directions():
+    """Sphere::fibonacci_sphere + ZenithY::into_normal (geo/sphere.rs:27-32,48-80): unit vectors, heights climbing
+    from -1 to +1 in steps of dydi = 2 / (count + d), zenith advancing by the golden angle."""
+    n = 20000
+    d = rtg.fibonacci_sphere(n, seed=3)
+    assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-12)
+    phi = np.pi * (3.0 - 5.0 ** 0.5)
+    dd = 2.0 * np.pi / phi
+    dydi = 2.0 / (n + dd)
+    i = np.arange(n)
+    y = d[:, 1]
+    # y = -1 + dydi (i + u) + dydi d v with u, v in [0, 1)
+    assert np.all(y >= -1.0 + dydi * i - 1e-15) and np.all(y < -1.0 + dydi * (i + 1 + dd))
+    assert np.all(np.diff(y[::8]) > 0)
+    # evenly spread: every octant holds about an eighth of the directions
+    octant = (d[:, 0] > 0) * 4 + (d[:, 1] > 0) * 2 + (d[:, 2] > 0)
+    assert np.abs(np.bincount(octant, minlength=8) / n - 0.125).max() < 0.01
+    assert np.array_equal(d, rtg.fibonacci_sphere(n, seed=3)) and not np.array_equal(d, rtg.fibonacci_sphere(n, seed=4))

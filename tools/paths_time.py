@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Photon-pass workload: rays leaving the two lights in n directions each (Fibonacci sphere), traced through the
-specular path trees of the glass sphere + checker plane + 1 M-triangle terrain scene with rtg_trace_paths.
+specular path trees of the glass sphere + checker plane + 1 M-triangle terrain scene with rtg_trace_paths
+(directions: Sphere::fibonacci_sphere of the host library, seeded).
 
     python tools/paths_time.py [directions_per_light] [max_depth]
 """
@@ -20,14 +21,6 @@ from raytracer_amd import rtg
 import bench
 
 
-def fibonacci_sphere(n):
-    """Evenly spread unit directions (the reference jitters them with its entropy-seeded generator, geo/sphere.rs)."""
-    i = np.arange(n, dtype=np.float64) + 0.5
-    phi = np.arccos(1.0 - 2.0 * i / n)
-    theta = np.pi * (1.0 + 5.0 ** 0.5) * i
-    return np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], axis=1)
-
-
 def main():
     per_light = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     max_depth = int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -41,7 +34,7 @@ def main():
     lights = np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
     scene = ctx.scene(list(objs) + [rtg.mesh_object(mesh, rtg.material((0.8, 0.7, 0.6)),
                                                      rtg.transform(1.0 / bench.LOCAL_SCALE))])
-    dirs = fibonacci_sphere(per_light)
+    dirs = rtg.fibonacci_sphere(per_light, seed=1)
     rays = np.concatenate([np.concatenate([np.broadcast_to(l["position"], dirs.shape), dirs], axis=1) for l in lights])
     n = rays.shape[0]
     d_rays = torch.from_numpy(np.ascontiguousarray(rays)).cuda()
