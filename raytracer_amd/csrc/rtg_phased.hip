@@ -447,8 +447,16 @@ struct PhasedParams {
 // sphere / plane hit, merged in when the ray retires.  COUNT builds tally node visits and triangle tests per ray;
 // KEEP builds (scenes with several meshes) hold the outer ray in LDS for the meshes after the first.  Point records are not built here: a streaming pass rebuilds them from the hit ids
 // (k_points_primary / k_points_batch), with every lane busy.
+#ifndef RTG_PHASED_BLOCK
+#define RTG_PHASED_BLOCK 64
+#endif
+// Threads per workgroup of the persistent kernel.  Waves never synchronise with each other, so the size only sets
+// the granularity at which the hardware hands finished waves' registers and LDS to the next launch.
+constexpr int kPhasedBlock = RTG_PHASED_BLOCK;
+static_assert(kPhasedBlock % 64 == 0 && kPhasedBlock >= 64 && kPhasedBlock <= 256, "one to four waves per workgroup");
+
 template <class Source, bool COUNT, bool PATCH, bool PRE, bool KEEP, bool STATS = false>
-__global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
+__global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
                                                           uint32_t *work_counters, PhasedParams prm,
                                                           rtg_hit *out_hits, rtg_ray_counters *out_counters,
                                                           const rtg_hit *__restrict__ prim_best) {
@@ -471,17 +479,17 @@ __global__ __launch_bounds__(kBlock, RTG_PHASED_WAVES) void k_trace_phased(DevSc
     bool has_ray = false;
     // Per-ray state that is only touched between objects lives in LDS ([field][lane], 8-byte fields, so a
     // wave's access is conflict-free): the outer ray, the output slot and the scene-level best hit.
-    extern __shared__ double cold[];      // 3 * kBlock doubles, or 9 * kBlock when prm.keep_outer
+    extern __shared__ double cold[];      // 3 * kPhasedBlock doubles, or 9 * kPhasedBlock when prm.keep_outer
     double *cold_lane = cold + threadIdx.x;
     enum { C_BEST_T = 0, C_BEST_ID, C_OUT, C_OX, C_OY, C_OZ, C_DX, C_DY, C_DZ };
-#define COLD(f) cold_lane[(f) * kBlock]
+#define COLD(f) cold_lane[(f) * kPhasedBlock]
     // A wave that takes a new 64-item chunk prepares all 64 rays at once (ray generation, transform into the first
     // mesh's space, pre-test ray) with every lane busy and parks them here ([field][slot of the wave]); a lane that
     // later needs a ray only copies one slot.
-    __shared__ double stage_d[6 * kBlock];
-    __shared__ uint32_t stage_u[(Source::kEarlyStop ? 10 : 8) * kBlock];
-#define STG_D(slot, f) stage_d[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
-#define STG_U(slot, f) stage_u[(f) * kBlock + (threadIdx.x & ~63u) + (slot)]
+    __shared__ double stage_d[6 * kPhasedBlock];
+    __shared__ uint32_t stage_u[(Source::kEarlyStop ? 10 : 8) * kPhasedBlock];
+#define STG_D(slot, f) stage_d[(f) * kPhasedBlock + (threadIdx.x & ~63u) + (slot)]
+#define STG_U(slot, f) stage_u[(f) * kPhasedBlock + (threadIdx.x & ~63u) + (slot)]
     const bool need_outer = KEEP;
     // the first mesh's constants, read once per wave
     const uint32_t first_id = (uint32_t)s.mesh_objects[0].index;
@@ -997,8 +1005,11 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     hipError_t e = hipMemsetAsync(work_counters, 0, (8 * kCounterStride + 16) * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     uint64_t chunks = (n_items + 63) >> 6;
-    uint64_t want = (chunks + 3) / 4;
-    uint32_t grid = (uint32_t)(want < tune.max_blocks ? want : tune.max_blocks);
+    // tune.max_blocks counts four-wave groups: the number of resident waves does not depend on the workgroup size
+    const uint64_t per_group = 256 / kPhasedBlock;
+    uint64_t want = (chunks + (kPhasedBlock / 64) - 1) / (kPhasedBlock / 64);
+    uint64_t most = (uint64_t)tune.max_blocks * per_group;
+    uint32_t grid = (uint32_t)(want < most ? want : most);
     if (grid == 0) grid = 1;
     // the outer ray is needed again when there are several meshes; only then does the dynamic LDS hold it (9 cold
     // fields per lane instead of 3)
@@ -1006,8 +1017,8 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     const bool keep = s.n_mesh_objects > 1;
     const bool pre = tune.pretest && s.any_f32_ok;
     PhasedParams prm{tune.tri_min, tune.obj_min, tune.patch_tri_min};
-    const size_t cold_bytes = (size_t)(keep ? 9 : 3) * kBlock * sizeof(double);
-    dim3 g(grid), b(kBlock);
+    const size_t cold_bytes = (size_t)(keep ? 9 : 3) * kPhasedBlock * sizeof(double);
+    dim3 g(grid), b(kPhasedBlock);
 #define RTG_L(C, X, P, K, S)                                                                                      \
     hipExtLaunchKernelGGL((k_trace_phased<Source, C, X, P, K, S>), g, b, cold_bytes, stream, tune.time_start,    \
                           tune.time_stop, 0, s, src, n_items, work_counters, prm, out_hits, out_counters, prim_best)
