@@ -11,9 +11,10 @@
 //     three sorts of all centres made once up front; equal centres share a rank, so ties keep their previous order
 //     exactly as the stable comparison sort keeps them.
 //   * the union of a segment's boxes (bvh_subdivide.rs:22 and BvhTree::add_node, bvh.rs:72-75) is a min/max
-//     reduction, exact in any order: lanes reduce runs of one segment inside the wave and the run heads finish
-//     with 64-bit integer atomics on an order-preserving image of the doubles (-0.0 below +0.0, as IEEE
-//     minimum/maximum order them, geo/bounds.rs:28-33).
+//     reduction, exact in any order: every lane walks a short stretch of the permutation, stores the box of a
+//     segment that lies wholly inside it, and the rest is combined across the wave and the workgroup before 64-bit
+//     integer atomics on an order-preserving image of the doubles (-0.0 below +0.0, as IEEE minimum/maximum
+//     order them, geo/bounds.rs:28-33).
 //   * the binary search for the split coordinate follows the probe order of the standard library the reference
 //     used (first probed equal element wins), then the 1 % / 99 % clamp (bvh_subdivide.rs:29-38).
 //
