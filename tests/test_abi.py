@@ -96,3 +96,25 @@ def test_scene_builder_defaults():
     assert list(view.orig) == [0.0, 0.0, 1.0]
     _, l25, _ = rtg.scene_builder(25)
     assert abs(l25[0]["position"][1] - 1.0) < 1e-15
+
+
+def test_header_is_plain_c_and_layouts_match_the_python_mirror(tmp_path):
+    """include/rtg.h compiles as C11 on its own (no C++ or framework types in the boundary), and the record sizes a
+    C caller sees are the ones the ctypes / numpy mirrors use."""
+    import subprocess
+    src = tmp_path / "sizes.c"
+    src.write_text(
+        '#include "rtg.h"\n#include <stdio.h>\n#include <stddef.h>\n'
+        'int main(void) {\n'
+        '  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(rtg_bvh_node), sizeof(rtg_tri), sizeof(rtg_hit),\n'
+        '         sizeof(rtg_point), sizeof(rtg_path), offsetof(rtg_path, point), sizeof(rtg_light), sizeof(rtg_view),\n'
+        '         sizeof(rtg_patch_leaf), sizeof(rtg_trispline));\n'
+        '  return 0;\n}\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [rtg.NODE_DTYPE.itemsize, 72, rtg.HIT_DTYPE.itemsize, rtg.POINT_DTYPE.itemsize, rtg.PATH_DTYPE.itemsize,
+                   rtg.PATH_DTYPE.fields["point"][1], rtg.LIGHT_DTYPE.itemsize, C.sizeof(rtg.View),
+                   rtg.PATCH_LEAF_DTYPE.itemsize, 240]
+    assert rtg.PATH_DTYPE.itemsize == 144
