@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +17,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rtg_launch.hpp"
@@ -269,6 +271,20 @@ void invert4(const double *m, double *n) {
     n[15] = det * (m00 * a1212 - m01 * a0212 + m02 * a0112);
 }
 
+// Splits [0, n) over a few host threads (mesh creation touches every node and triangle of trees with tens of
+// millions of records).
+template <class F> void parallel_ranges(size_t n, F f) {
+    unsigned t = std::thread::hardware_concurrency();
+    if (t > 16) t = 16;
+    if (t < 2 || n < (1u << 16)) {
+        f((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < t; w++) pool.emplace_back([=]() { f(n * w / t, n * (w + 1) / t); });
+    for (auto &th : pool) th.join();
+}
+
 // Walks the caller's tree from the root: checks every range, rejects shared or
 // cyclic nodes, and emits (a) the reference-order node array with a
 // "last sibling" flag per node and (b) the pre-order threaded array with skip
@@ -282,21 +298,33 @@ int layout_tree(rtg_ctx *ctx, const rtg_bvh *bvh, std::vector<DevNode> &ref_node
     depth_out = 0;
     if (nn == 0) return RTG_OK;
     if (bvh->root >= nn) return fail(ctx, RTG_E_INVALID, "bvh root %u out of range (%llu nodes)", bvh->root, (unsigned long long)nn);
-    for (uint64_t i = 0; i < nn; i++) {
+    std::atomic<uint64_t> bad_node(UINT64_MAX);
+    parallel_ranges((size_t)nn, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+            const rtg_bvh_node &s = bvh->nodes[i];
+            if (s.child_begin > s.child_end || s.child_end > nn || s.leaf_begin > s.leaf_end || s.leaf_end > nl) {
+                uint64_t seen = bad_node.load();
+                while (i < seen && !bad_node.compare_exchange_weak(seen, (uint64_t)i)) {
+                }
+                continue;
+            }
+            DevNode &d = ref_nodes[i];
+            for (int k = 0; k < 3; k++) {
+                d.lo[k] = s.lo[k];
+                d.hi[k] = s.hi[k];
+            }
+            d.link = s.child_begin;
+            d.nchild = s.child_end - s.child_begin;
+            d.leaf_begin = s.leaf_begin;
+            d.leaf_count = s.leaf_end - s.leaf_begin;
+        }
+    });
+    if (bad_node.load() != UINT64_MAX) {
+        const uint64_t i = bad_node.load();
         const rtg_bvh_node &s = bvh->nodes[i];
         if (s.child_begin > s.child_end || s.child_end > nn)
             return fail(ctx, RTG_E_INVALID, "bvh node %llu: child range [%u,%u) invalid", (unsigned long long)i, s.child_begin, s.child_end);
-        if (s.leaf_begin > s.leaf_end || s.leaf_end > nl)
-            return fail(ctx, RTG_E_INVALID, "bvh node %llu: leaf range [%u,%u) invalid", (unsigned long long)i, s.leaf_begin, s.leaf_end);
-        DevNode &d = ref_nodes[(size_t)i];
-        for (int k = 0; k < 3; k++) {
-            d.lo[k] = s.lo[k];
-            d.hi[k] = s.hi[k];
-        }
-        d.link = s.child_begin;
-        d.nchild = s.child_end - s.child_begin;
-        d.leaf_begin = s.leaf_begin;
-        d.leaf_count = s.leaf_end - s.leaf_begin;
+        return fail(ctx, RTG_E_INVALID, "bvh node %llu: leaf range [%u,%u) invalid", (unsigned long long)i, s.leaf_begin, s.leaf_end);
     }
     std::vector<uint8_t> seen((size_t)nn, 0);
     struct Frame {
@@ -546,11 +574,13 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) {
     rc = layout_tree(ctx, bvh, ref_nodes, thr_nodes, depth);
     if (rc != RTG_OK) return rc;
     std::vector<DevTri> tris((size_t)bvh->n_leaves);
-    for (uint64_t i = 0; i < bvh->n_leaves; i++) {
-        std::memcpy(tris[(size_t)i].p, bvh->leaves[i].p, sizeof(double) * 9);
-        tris[(size_t)i].source = (uint32_t)i;
-        tris[(size_t)i].pad = 0;
-    }
+    parallel_ranges(tris.size(), [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+            std::memcpy(tris[i].p, bvh->leaves[i].p, sizeof(double) * 9);
+            tris[i].source = (uint32_t)i;
+            tris[i].pad = 0;
+        }
+    });
 
     rtg_mesh *m = new (std::nothrow) rtg_mesh();
     if (!m) return fail(ctx, RTG_E_NOMEM, "out of host memory");
@@ -566,22 +596,38 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) {
     // single-precision companion nodes for the pre-test, and the windows inside which the reciprocal-based and the
     // single-precision box tests are exact (see rtg_phased.hip)
     std::vector<HotNode> hot(thr_nodes.size());
-    uint32_t fast_ok = 1, f32_ok = 1;
-    double cmax = 0.0;
-    for (size_t i = 0; i < thr_nodes.size(); i++) {
-        const DevNode &n = thr_nodes[i];
-        for (int k = 0; k < 3; k++) {
-            hot[i].planes[2 * k] = (float)n.lo[k];
-            hot[i].planes[2 * k + 1] = (float)n.hi[k];
-            for (double c : {n.lo[k], n.hi[k]}) {
-                double a = std::fabs(c);
-                if (!(c == 0.0 || (a >= 0x1p-600 && a <= 0x1p400))) fast_ok = 0;
-                if (!(c == 0.0 || (a >= 0x1p-40 && a <= 0x1p40))) f32_ok = 0;
-                if (a > cmax) cmax = a;
+    std::atomic<uint32_t> not_fast(0), not_f32(0);
+    std::atomic<uint64_t> cmax_bits(0);          // bits of the largest |coordinate| (non-negative doubles order as integers)
+    parallel_ranges(thr_nodes.size(), [&](size_t b, size_t e) {
+        uint32_t nf = 0, n32 = 0;
+        double local_max = 0.0;
+        for (size_t i = b; i < e; i++) {
+            const DevNode &n = thr_nodes[i];
+            for (int k = 0; k < 3; k++) {
+                hot[i].planes[2 * k] = (float)n.lo[k];
+                hot[i].planes[2 * k + 1] = (float)n.hi[k];
+                for (double c : {n.lo[k], n.hi[k]}) {
+                    double a = std::fabs(c);
+                    if (!(c == 0.0 || (a >= 0x1p-600 && a <= 0x1p400))) nf = 1;
+                    if (!(c == 0.0 || (a >= 0x1p-40 && a <= 0x1p40))) n32 = 1;
+                    if (a > local_max) local_max = a;
+                }
             }
+            hot[i].skip = n.link;
+            hot[i].leaf_ref = n.leaf_count == 0 ? 0xFFFFFFFFu : (n.leaf_count == 1 ? n.leaf_begin : 0x80000000u);
         }
-        hot[i].skip = n.link;
-        hot[i].leaf_ref = n.leaf_count == 0 ? 0xFFFFFFFFu : (n.leaf_count == 1 ? n.leaf_begin : 0x80000000u);
+        if (nf) not_fast.store(1);
+        if (n32) not_f32.store(1);
+        uint64_t mine, seen = cmax_bits.load();
+        std::memcpy(&mine, &local_max, 8);
+        while (mine > seen && !cmax_bits.compare_exchange_weak(seen, mine)) {
+        }
+    });
+    const uint32_t fast_ok = not_fast.load() ? 0u : 1u, f32_ok = not_f32.load() ? 0u : 1u;
+    double cmax;
+    {
+        uint64_t bits = cmax_bits.load();
+        std::memcpy(&cmax, &bits, 8);
     }
 
     // one slab: header, hot nodes, threaded nodes, triangles
