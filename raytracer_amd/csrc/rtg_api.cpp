@@ -1199,7 +1199,8 @@ int rtg_trace_paths(rtg_scene *scene, const double *rays6, uint64_t n_rays, uint
         HIP_TRY(ctx, launch_path_emit(ctx->stream, (const SpecMeta *)meta, (const rtg_point *)pts, m, max_depth, cnt + 3,
                                       (uint64_t *)keys, (rtg_path *)recs));
         const bool deeper = depth + 1 < max_depth;
-        if (deeper) HIP_TRY(ctx, launch_spec_count(ctx->stream, ds, (const rtg_point *)pts, m, cnt + 2));
+        // the batch's refracting hits are counted to size level 1; below, a level's own size bounds the next
+        if (deeper && depth == 0) HIP_TRY(ctx, launch_spec_count(ctx->stream, ds, (const rtg_point *)pts, m, cnt + 2));
         if ((rc = read_counters()) != RTG_OK) return rc;
         level_records[n_levels] = (const rtg_path *)recs;
         level_keys[n_levels] = (const uint64_t *)keys;
@@ -1209,7 +1210,7 @@ int rtg_trace_paths(rtg_scene *scene, const double *rays6, uint64_t n_rays, uint
         total += host_cnt[3];
         if (total >= (1ull << 32)) return fail(ctx, RTG_E_LIMIT, "rtg_trace_paths: more than 2^32 paths");
         uint64_t m_next = 0;
-        const uint32_t k = host_cnt[2];
+        const uint32_t k = depth == 0 ? host_cnt[2] : (uint32_t)m;
         if (deeper && k != 0) {
             const std::string next_tag = std::to_string(depth + 1);
             void *next_rays = nullptr, *next_meta = nullptr;
@@ -1314,10 +1315,16 @@ int frame_wavefront(rtg_ctx *ctx, const DevScene &ds, const rtg_view &view, uint
         const int nxt = depth == 0 ? 0 : cur ^ 1;
         if (spec && depth + 1 < max_depth && m != 0) {
             HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), ctx->stream));
-            HIP_TRY(ctx, hipMemsetAsync(cnt + 2, 0, sizeof(uint32_t), ctx->stream));
-            HIP_TRY(ctx, launch_spec_count(ctx->stream, ds, pts, m, cnt + 2));
-            if ((rc = read_counters()) != RTG_OK) return rc;
-            const uint32_t k = host_cnt[2];
+            // How many rays of this level hit a refracting material bounds the next level (two rays each).  Level 0
+            // counts them (the slot table is sized by it); below, every ray descends from a refracting hit and the
+            // level's own size is bound enough, which saves a pass over the points and a read-back per level.
+            uint32_t k = (uint32_t)m;
+            if (depth == 0) {
+                HIP_TRY(ctx, hipMemsetAsync(cnt + 2, 0, sizeof(uint32_t), ctx->stream));
+                HIP_TRY(ctx, launch_spec_count(ctx->stream, ds, pts, m, cnt + 2));
+                if ((rc = read_counters()) != RTG_OK) return rc;
+                k = host_cnt[2];
+            }
             if (k != 0 && depth == 0) {
                 n_groups = k;
                 const size_t slot_bytes = (size_t)n_groups * slots_per_group * 4 * sizeof(double);
