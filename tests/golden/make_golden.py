@@ -47,7 +47,31 @@ def mesh_scene():
                         ray_seed=10212233, ray_hits=rhits, ray_counters=rctr)
 
 
+def paths_and_builders():
+    """Specular path records of seeded rays into the default scene (glass sphere over the checker plane), and the
+    leaf orders of the three builders on a small terrain."""
+    objs, lights, view = scenes.default_objects(7)
+    pair = scenes.Pair(None, objs, {})
+    rays = path_rays()
+    paths = pair.cpu.trace_paths(rays, max_depth=4)
+    tris, _ = scenes.terrain(9, 7, seed=11)
+    orders = {s: orc.OracleBvh(tris, strategy=s).leaf_source() for s in ("subdivide", "contract", "hybrid")}
+    np.savez_compressed(os.path.join(HERE, "paths_and_builders.npz"), time=7, paths=paths, grid=(9, 7), seed=11,
+                        **{"leaf_source_" + k: v for k, v in orders.items()})
+
+
+def path_rays():
+    rays = rtg.bench_mesh_rays([-0.3, -0.3, 0.8, 0.3, 0.3, 1.0], 600, seed=77)
+    rays[:, 3:] = np.array([0.0, -0.2, -1.0]) + 0.3 * rays[:, 3:]
+    rays[:, 3:] /= np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+    return rays
+
+
 if __name__ == "__main__":
+    if "new" in sys.argv[1:]:                 # only the vectors added last; the older files stay byte-identical
+        paths_and_builders()
+        sys.exit(0)
     default_scene()
     mesh_scene()
+    paths_and_builders()
     print("golden vectors written to", HERE)

@@ -63,6 +63,46 @@ def test_oracle_and_host_builder_reproduce_terrain_golden():
     assert scenes.same_hits(rhits, g["ray_hits"]) and np.array_equal(rctr, g["ray_counters"])
 
 
+def _path_rays():
+    rays = rtg.bench_mesh_rays([-0.3, -0.3, 0.8, 0.3, 0.3, 1.0], 600, seed=77)
+    rays[:, 3:] = np.array([0.0, -0.2, -1.0]) + 0.3 * rays[:, 3:]
+    rays[:, 3:] /= np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+    return rays
+
+
+def _paths_equal(a, b):
+    if a.shape != b.shape:
+        return False
+    for f in ("ray", "depth", "modes", "parent"):
+        if not np.array_equal(a[f], b[f]):
+            return False
+    return not scenes.float_bits_differ(a["attenuation"], b["attenuation"]).any() and _points_equal(a["point"], b["point"])
+
+
+def test_oracle_and_host_builders_reproduce_paths_and_builder_golden():
+    import orc
+    g = _load("paths_and_builders.npz")
+    objs, lights, view = scenes.default_objects(int(g["time"]))
+    pair = scenes.Pair(None, objs, {})
+    paths = pair.cpu.trace_paths(_path_rays(), max_depth=4)
+    assert _paths_equal(paths, g["paths"])
+    assert (g["paths"]["depth"] == 3).sum() > 50 and (g["paths"]["modes"] != 0).sum() > 100
+    tris, _ = scenes.terrain(int(g["grid"][0]), int(g["grid"][1]), seed=int(g["seed"]))
+    for strategy in ("subdivide", "contract", "hybrid"):
+        want = g["leaf_source_" + strategy]
+        assert np.array_equal(orc.OracleBvh(tris, strategy=strategy).leaf_source(), want)
+        assert np.array_equal(rtg.HostBvh(tris, strategy=strategy).leaf_source(), want)
+    assert not np.array_equal(g["leaf_source_contract"], g["leaf_source_subdivide"])
+
+
+@pytest.mark.gpu
+def test_gpu_paths_match_golden(gpu_ctx):
+    g = _load("paths_and_builders.npz")
+    objs, lights, view = scenes.default_objects(int(g["time"]))
+    pair = scenes.Pair(gpu_ctx, objs, {})
+    assert _paths_equal(pair.gpu.trace_paths(_path_rays(), max_depth=4), g["paths"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("traversal", [0, 1, 2])
 def test_gpu_matches_golden(gpu_ctx, traversal):
