@@ -25,6 +25,10 @@
  *  - one rtg_ctx per GPU; calls on one ctx are serialised by the caller
  *    (mirrors the single `&mut self` caller of Renderer::render); distinct
  *    contexts may be driven from distinct host threads.
+ *  - lifetimes: a scene runs its calls on the context that created it, so
+ *    destroy scenes before their context.  A mesh only remembers its GPU: it
+ *    may outlive the context that created it, be shared by scenes of other
+ *    contexts on the same GPU, and must outlive every scene that uses it.
  */
 #ifndef RTG_H
 #define RTG_H
@@ -262,6 +266,7 @@ int rtg_transform_from_forward(const double forward[16], rtg_transform *out);
  * (src/render/mesh_object.rs:10-13).  The tree is validated (ranges in
  * bounds, acyclic, every node reachable at most once). */
 int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out);
+/* (every node must be reachable from `root`, as in a tree made by Bvh::new) */
 void rtg_mesh_destroy(rtg_mesh *mesh);
 /* A facet BVH whose leaves stand for trispline patches (object kind
  * RTG_PATCHES); `bvh` is the flattened tree over the facets, built like any
@@ -281,7 +286,8 @@ int rtg_mesh_build_patches(rtg_ctx *ctx, const rtg_tri *facets, uint64_t n_facet
                            rtg_mesh **out);
 /* Node and leaf counts, root index (`Bvh::root`) and depth of a mesh's flattened tree; any pointer may be NULL. */
 int rtg_mesh_sizes(const rtg_mesh *mesh, uint64_t *n_nodes, uint64_t *n_leaves, uint32_t *root, uint32_t *depth);
-/* Copies a mesh's flattened tree back to host arrays sized by rtg_mesh_sizes: `nodes` in the order of
+/* Copies a mesh's flattened tree back to host arrays sized by rtg_mesh_sizes (blocking; waits for the GPU's
+ * outstanding work; failures are reported through rtg_last_error(NULL)): `nodes` in the order of
  * `Bvh::nodes`, `leaves` in the order of `Bvh::leaves` (src/tree/bvh.rs:20-24), `leaf_source[l]` = index of leaf
  * l's triangle in the array given to rtg_mesh_build (the identity for rtg_mesh_create).  Any pointer may be NULL. */
 int rtg_mesh_read_bvh(const rtg_mesh *mesh, rtg_bvh_node *nodes, rtg_tri *leaves, uint32_t *leaf_source);

@@ -53,7 +53,7 @@ struct rtg_ctx {
 };
 
 struct rtg_mesh {
-    rtg_ctx *ctx = nullptr;
+    int device = 0;                  // a mesh may outlive the context that made it: only the GPU is remembered
     DevMesh dev{};
     void *d_nodes = nullptr, *d_slab = nullptr, *d_normals = nullptr;
     void *d_patches = nullptr, *d_leaf_info = nullptr;
@@ -64,7 +64,8 @@ struct rtg_mesh {
 };
 
 struct rtg_scene {
-    rtg_ctx *ctx = nullptr;
+    rtg_ctx *ctx = nullptr;          // calls on the scene run on this context: it must outlive the scene's last call
+    int device = 0;                  // rtg_scene_destroy only needs the GPU
     DevScene dev{};
     void *d_objects = nullptr, *d_mesh_objects = nullptr;
     uint32_t max_depth = 0;
@@ -117,10 +118,12 @@ bool is_device_pointer(const void *p) {
 
 int scratch_get(rtg_ctx *ctx, const char *name, size_t bytes, void **out);
 
-// Tuning of one timed launch: with "time_kernels" on, an event pair for the launch's execution window.
-int tuning_for_launch(rtg_ctx *ctx, PhasedTuning &t) {
+// Tuning of one timed launch: with "time_kernels" on, an event pair for the launch's execution window.  Only a
+// launch of the persistent kernel fills the pair (`will_launch`: the scene has a mesh and there is work), so only
+// then is one handed out.
+int tuning_for_launch(rtg_ctx *ctx, bool will_launch, PhasedTuning &t) {
     t = ctx->tune;
-    if (!ctx->time_kernels) return RTG_OK;
+    if (!ctx->time_kernels || !will_launch) return RTG_OK;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (!ctx->idle_events.empty()) {
         ev = ctx->idle_events.back();
@@ -509,14 +512,23 @@ int rtg_ctx_kernel_time(rtg_ctx *ctx, double *total_ms, uint64_t *launches) {
     int rc = bind_device(ctx);
     if (rc != RTG_OK) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // every pair goes back to the idle list whatever happens, so one bad pair cannot poison later calls
+    hipError_t first_error = hipSuccess;
     for (auto &ev : ctx->timed) {
         float ms = 0.0f;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
-        *total_ms += (double)ms;
-        *launches += 1;
+        hipError_t e = hipEventElapsedTime(&ms, ev.first, ev.second);
+        if (e == hipSuccess) {
+            *total_ms += (double)ms;
+            *launches += 1;
+        } else {
+            (void)hipGetLastError();
+            if (first_error == hipSuccess) first_error = e;
+        }
     }
     ctx->idle_events.insert(ctx->idle_events.end(), ctx->timed.begin(), ctx->timed.end());
     ctx->timed.clear();
+    if (first_error != hipSuccess)
+        return fail(ctx, RTG_E_HIP, "rtg_ctx_kernel_time: a launch's events were never filled: %s", hipGetErrorString(first_error));
     return RTG_OK;
 }
 
@@ -573,6 +585,11 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) {
     uint32_t depth = 0;
     rc = layout_tree(ctx, bvh, ref_nodes, thr_nodes, depth);
     if (rc != RTG_OK) return rc;
+    // Bvh::new (src/tree/bvh.rs:80-106) only ever emits nodes below the root; a tree with stray entries would make
+    // the reference-order array (indexed by the caller's ids) and the reachable count disagree
+    if (thr_nodes.size() != (size_t)bvh->n_nodes)
+        return fail(ctx, RTG_E_INVALID, "bvh has %llu nodes but only %zu are reachable from the root",
+                    (unsigned long long)bvh->n_nodes, thr_nodes.size());
     std::vector<DevTri> tris((size_t)bvh->n_leaves);
     parallel_ranges(tris.size(), [&](size_t b, size_t e) {
         for (size_t i = b; i < e; i++) {
@@ -584,7 +601,7 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) {
 
     rtg_mesh *m = new (std::nothrow) rtg_mesh();
     if (!m) return fail(ctx, RTG_E_NOMEM, "out of host memory");
-    m->ctx = ctx;
+    m->device = ctx->device;
     m->n_leaves = bvh->n_leaves;
     if (bvh->n_nodes) {
         const rtg_bvh_node &r = bvh->nodes[bvh->root];
@@ -681,7 +698,7 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) {
 
 void rtg_mesh_destroy(rtg_mesh *m) {
     if (!m) return;
-    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    (void)hipSetDevice(m->device);
     if (m->d_nodes) (void)hipFree(m->d_nodes);
     if (m->d_slab) (void)hipFree(m->d_slab);
     if (m->d_normals) (void)hipFree(m->d_normals);
@@ -806,7 +823,7 @@ int rtg_mesh_build(rtg_ctx *ctx, const rtg_tri *triangles, uint64_t n_triangles,
         if (built.d_normals) (void)hipFree(built.d_normals);
         return fail(ctx, RTG_E_NOMEM, "out of host memory");
     }
-    m->ctx = ctx;
+    m->device = ctx->device;
     m->n_leaves = n_triangles;
     m->d_slab = built.d_slab;
     m->d_nodes = built.d_nodes;
@@ -898,11 +915,12 @@ int rtg_mesh_sizes(const rtg_mesh *mesh, uint64_t *n_nodes, uint64_t *n_leaves, 
 }
 
 int rtg_mesh_read_bvh(const rtg_mesh *mesh, rtg_bvh_node *nodes, rtg_tri *leaves, uint32_t *leaf_source) {
-    if (!mesh || !mesh->ctx) return fail(nullptr, RTG_E_INVALID, "null mesh");
-    rtg_ctx *ctx = mesh->ctx;
-    int rc = bind_device(ctx);
-    if (rc != RTG_OK) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!mesh) return fail(nullptr, RTG_E_INVALID, "null mesh");
+    // no context is involved: the mesh is immutable after creation and the copies below are blocking (errors are
+    // reported through rtg_last_error(NULL))
+    rtg_ctx *ctx = nullptr;
+    HIP_TRY(ctx, hipSetDevice(mesh->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
     const size_t nn = mesh->dev.n_nodes, nl = (size_t)mesh->n_leaves;
     const size_t chunk = 1u << 16;
     if (nodes && nn) {
@@ -986,7 +1004,7 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
         case RTG_PATCHES:
             if (!o.mesh) return fail(ctx, RTG_E_INVALID, "object %u: mesh handle is null", i);
             // a mesh is immutable once created, so contexts of one GPU may share it (several frames in flight)
-            if (o.mesh->ctx != ctx && o.mesh->ctx->device != ctx->device)
+            if (o.mesh->device != ctx->device)
                 return fail(ctx, RTG_E_INVALID, "object %u: mesh belongs to a context on another GPU", i);
             if ((o.kind == RTG_PATCHES) != o.mesh->is_patches)
                 return fail(ctx, RTG_E_INVALID, "object %u: kind %d does not match the mesh handle (%s)", i, o.kind,
@@ -1001,6 +1019,7 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
     rtg_scene *s = new (std::nothrow) rtg_scene();
     if (!s) return fail(ctx, RTG_E_NOMEM, "out of host memory");
     s->ctx = ctx;
+    s->device = ctx->device;
     s->max_depth = max_depth;
     rc = upload(ctx, objs.data(), objs.size() * sizeof(DevObject), &s->d_objects);
     if (rc != RTG_OK) {
@@ -1045,7 +1064,7 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
 
 void rtg_scene_destroy(rtg_scene *s) {
     if (!s) return;
-    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    (void)hipSetDevice(s->device);
     if (s->d_objects) (void)hipFree(s->d_objects);
     if (s->d_mesh_objects) (void)hipFree(s->d_mesh_objects);
     delete s;
@@ -1077,7 +1096,7 @@ int rtg_render_primary(rtg_scene *scene, const rtg_view *view, uint32_t width, u
         if ((rc = phased_scratch(ctx, ds, n, ps)) != RTG_OK) return rc;
         if (op.dev && !hits && (rc = scratch_get(ctx, "points_hits", n * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
         PhasedTuning tune;
-        if ((rc = tuning_for_launch(ctx, tune)) != RTG_OK) return rc;
+        if ((rc = tuning_for_launch(ctx, ds.n_mesh_objects != 0, tune)) != RTG_OK) return rc;
         HIP_TRY(ctx, launch_render_primary_phased(ctx->stream, ds, *view, width, height, tile, ps, tune,
                                                   (rtg_hit *)hits, (rtg_ray_counters *)oc.dev));
         if (op.dev)
@@ -1120,7 +1139,7 @@ int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *o
         if ((rc = phased_scratch(ctx, ds, n_rays, ps)) != RTG_OK) return rc;
         if (op.dev && !hits && (rc = scratch_get(ctx, "points_hits", n_rays * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
         PhasedTuning tune;
-        if ((rc = tuning_for_launch(ctx, tune)) != RTG_OK) return rc;
+        if ((rc = tuning_for_launch(ctx, ds.n_mesh_objects != 0, tune)) != RTG_OK) return rc;
         HIP_TRY(ctx, launch_trace_phased(ctx->stream, ds, (const double *)d_rays, n_rays, ps, tune,
                                          (rtg_hit *)hits, (rtg_ray_counters *)oc.dev));
         if (op.dev)

@@ -121,8 +121,13 @@ struct ShadowSource {
     uint64_t n_points;
     uint32_t n_lights;
     // compute_direct_irrad only asks whether the closest hit lies before the light (`occ.t < dis`,
-    // render/renderer.rs:184-205).  The first accepted hit below `dis` settles that: the reference's own traversal
-    // meets the same hit in the same state, and its final minimum can only be lower.
+    // render/renderer.rs:184-205).  Within one mesh the first accepted hit below `dis` settles that mesh: the
+    // reference's own traversal meets the same hit in the same state, and the holder only ever replaces it by a
+    // lower time.  Across objects the scene takes `.min()` under real_cmp (render/scene_object.rs:31-34), where a
+    // NaN time -- a zero-area triangle met while its mesh's holder is empty -- orders below every number and makes
+    // `occ.t < dis` false.  So a ray that ended its walk of one mesh early still walks the meshes after it, but
+    // only up to their first accepted hit (the only one that can be NaN), and every result goes through the scene
+    // minimum.
     __device__ __forceinline__ double stop_time(uint64_t item) const {
         uint64_t l = item / n_points, p = item - l * n_points;
         const rtg_point &pt = points[p];
@@ -509,8 +514,7 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
     uint32_t leaf_cur = 0;        // next leaf to test; bit 31: the node (cur - 1) has several leaves, its range ends the TRI phase
     GBytePtr slab = nullptr;      // the current mesh's hot-node array (slab + 64); everything else is an offset
     bool pre = false;             // this ray/mesh pair may use the single-precision pre-test
-    double t_stop = -kInf;        // sources with kEarlyStop: a held hit below this time ends the query
-    bool stopped = false;
+    double t_stop = -kInf;        // sources with kEarlyStop: a held hit below this time ends the walk of a mesh
     // single-precision ray for the pre-test: reciprocal direction, -(origin * reciprocal), error bound, and the
     // holder's bound rounded to f32
     float r32x = 0, r32y = 0, r32z = 0, np32x = 0, np32y = 0, np32z = 0, e2 = 0, b32 = 0;
@@ -645,7 +649,6 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
                             obj_i = 0;
                             if (Source::kEarlyStop) {
                                 t_stop = __longlong_as_double((long long)(((uint64_t)STG_U(slot, 9) << 32) | STG_U(slot, 8)));
-                                stopped = false;
                             }
                             uint64_t out_index = src.slot_of(item);
                             if (need_outer) {
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
                     if (PRE) b32 = (float)h.t;       // an empty holder keeps t = +inf
                     leaf_done();
                     if (Source::kEarlyStop && h.has && h.t < t_stop) {
-                        stopped = true;
+                        t_stop = kInf;       // later meshes: any accepted hit with a finite time ends their walk
                         phase = PH_DONE;
                     }
                 }
@@ -867,7 +870,7 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
                     if (PRE) b32 = (float)h.t;
                     leaf_done();
                     if (Source::kEarlyStop && h.has && h.t < t_stop) {
-                        stopped = true;
+                        t_stop = kInf;       // later meshes: any accepted hit with a finite time ends their walk
                         phase = PH_DONE;
                     }
                 }
@@ -893,7 +896,7 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
                     COLD(C_BEST_ID) = __longlong_as_double((long long)(((uint64_t)h.leaf << 32) | id));
                 }
             }
-            obj_i = (Source::kEarlyStop && stopped) ? s.n_mesh_objects : obj_i + 1;
+            obj_i = obj_i + 1;
             phase = PH_OBJ;
         }
     }

@@ -5,6 +5,7 @@ Only plain pointers and sizes cross the boundary.  Arrays are numpy arrays
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -388,6 +389,7 @@ class Context:
             raise RtgError(rc, lib.rtg_last_error(None).decode())
         self._h = h
         self.device = device
+        self._scenes = weakref.WeakSet()      # scenes run on their context: they are closed before it
 
     def _check(self, rc):
         if rc != 0:
@@ -439,6 +441,8 @@ class Context:
 
     def close(self):
         if self._h:
+            for sc in list(self._scenes):
+                sc.close()
             lib.rtg_ctx_destroy(self._h)
             self._h = None
 
@@ -522,7 +526,9 @@ class Mesh:
         nodes = np.zeros(nn, dtype=NODE_DTYPE)
         leaves = np.zeros((nl, 3, 3))
         source = np.zeros(nl, dtype=np.uint32)
-        self.ctx._check(lib.rtg_mesh_read_bvh(self._h, _ptr(nodes), _ptr(leaves), _ptr(source)))
+        rc = lib.rtg_mesh_read_bvh(self._h, _ptr(nodes), _ptr(leaves), _ptr(source))
+        if rc != 0:
+            raise RtgError(rc, lib.rtg_last_error(None).decode())
         return nodes, leaves, source
 
     def close(self):
@@ -588,6 +594,7 @@ class Scene:
         h = _vp()
         ctx._check(lib.rtg_scene_create(ctx._h, C.byref(desc), C.byref(h)))
         self._h = h
+        ctx._scenes.add(self)
 
     def render_primary(self, view, width, height, tile=None, points=False, counters=False, out_hits=None):
         """Host-buffer convenience: returns (hits, points|None, counters|None) as numpy arrays over the tile."""

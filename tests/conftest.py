@@ -18,3 +18,16 @@ def gpu_ctx():
     ctx = rtg.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(autouse=True)
+def _restore_ctx_options(request):
+    """Context options are state of the shared session context: whatever a test sets (or leaves set when it fails
+    half way) is put back to the library defaults before the next test runs."""
+    yield
+    if "gpu_ctx" in request.fixturenames:
+        ctx = request.getfixturevalue("gpu_ctx")
+        for key, value in (("traversal", 2), ("pretest", 2), ("frame_bands", 2), ("time_kernels", 1), ("stats", 1),
+                           ("tri_min", 20), ("obj_min", 4), ("patch_tri_min", 24), ("max_blocks", 1024)):
+            ctx.set_option(key, value)
+        ctx.set_stream(None)

@@ -99,3 +99,27 @@ def patch_scene_objects(xform, with_default=True, time=0, diffuse=(0.7, 0.8, 0.6
 def same_hits(a, b):
     """Bit-exact comparison of two HIT_DTYPE arrays."""
     return hit_mismatches(a.reshape(-1), b.reshape(-1)).size == 0
+
+
+def shadow_corner_scene(order):
+    """A checker floor under a canopy of ordinary triangles (mesh X) and, higher up, a mesh Y that holds zero-area
+    triangles (v2 == v1: NaN hit time, src/geo/triangle.rs:54-82) next to a few ordinary ones.  A shadow ray from the
+    floor that is blocked by X and then meets a zero-area triangle of Y while Y's holder is empty is NOT occluded in
+    the reference: the scene's `.min()` orders the NaN time lowest (src/render/scene_object.rs:31-34,
+    src/math/scalar.rs:46-60) and `occ.time < dis` is false (src/render/renderer.rs:197-201).
+    order 0: [floor, X, Y]; order 1: [floor, Y, X].  Returns (objects, {index: HostBvh}, index of Y)."""
+    rng = np.random.default_rng(42)
+    c = np.stack([rng.uniform(-0.8, 0.8, 300), rng.uniform(-0.25, 0.0, 300), rng.uniform(-1.2, 0.3, 300)], axis=1)
+    canopy = c[:, None, :] + rng.uniform(-0.1, 0.1, size=(300, 3, 3))
+    a = np.stack([rng.uniform(-0.7, 0.7, 16), rng.uniform(0.25, 0.6, 16), rng.uniform(-0.6, 0.7, 16)], axis=1)
+    b = a + rng.uniform(0.15, 0.45, size=(16, 3)) * rng.choice([-1.0, 1.0], size=(16, 3))
+    slivers = np.stack([a, b, b], axis=1)
+    few = c[:30, None, :] + [0, 0.45, 0] + rng.uniform(-0.05, 0.05, size=(30, 3, 3))
+    floor = rtg.plane_object((0, -0.5, 0), (0, 0, -1), (-1, 0, 0), rtg.material((1.0, 1.0, 1.0)), rtg.material((0.1, 0.1, 0.1)))
+    mx = rtg.mesh_object(None, rtg.material((0.8, 0.7, 0.6)))
+    my = rtg.mesh_object(None, rtg.material((0.3, 0.7, 0.9)))
+    bx = rtg.HostBvh(np.ascontiguousarray(canopy))
+    by = rtg.HostBvh(np.ascontiguousarray(np.concatenate([slivers, few])))
+    if order == 0:
+        return [floor, mx, my], {1: bx, 2: by}, 2
+    return [floor, my, mx], {1: by, 2: bx}, 1

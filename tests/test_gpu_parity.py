@@ -326,6 +326,41 @@ def test_frame_of_opaque_scene_in_passes(gpu_ctx, traversal):
 
 
 @pytest.mark.parametrize("traversal", TRAVERSALS)
+@pytest.mark.parametrize("order", [0, 1])
+def test_shadow_ray_meets_nan_hit_in_another_mesh(gpu_ctx, traversal, order):
+    """compute_direct_irrad (src/render/renderer.rs:184-205) with two meshes on the shadow path, one of them holding
+    zero-area triangles: a NaN-time hit in any mesh wins the scene's `.min()` and un-occludes the light, also when
+    another mesh -- before or after it in the object list -- blocks the ray."""
+    gpu_ctx.set_option("traversal", traversal)
+    try:
+        objs, meshes, yi = scenes.shadow_corner_scene(order)
+        _, lights, view = scenes.default_objects(17)
+        pair = scenes.Pair(gpu_ctx, objs, meshes)
+        w, h = 200, 150
+        for tile in (None, (9, 60, 180, 85)):
+            g_rgb, g_c8, g_hits = pair.gpu.render_frame(view, lights, w, h, tile=tile, max_depth=4)
+            c_rgb, c_c8, c_hits = pair.cpu.render_frame(view, lights, w, h, tile=tile, max_depth=4)
+            _assert_hits_equal(g_hits, c_hits)
+            assert not scenes.float_bits_differ(g_rgb, c_rgb).any()
+            assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1
+        # the same through rtg_shade_direct on already-built points
+        _, g_pts, _ = pair.gpu.render_primary(view, w, h, points=True)
+        g_rgb, g_c8 = pair.gpu.shade_direct(lights, g_pts, rgba8=True)
+        s_rgb, s_c8 = pair.cpu.shade_direct(lights, g_pts, rgba8=True)
+        assert not scenes.float_bits_differ(g_rgb, s_rgb).any()
+        assert np.abs(g_c8.astype(int) - s_c8.astype(int)).max() <= 1
+        # the scene does exercise the corner: without the mesh of zero-area triangles many floor pixels are darker
+        keep = [i for i in range(len(objs)) if i != yi]
+        without = scenes.Pair(None, [objs[i] for i in keep], {keep.index(i): m for i, m in meshes.items() if i != yi})
+        o_rgb, _, o_hits = without.cpu.render_frame(view, lights, w, h, max_depth=4)
+        c_rgb, _, c_hits = pair.cpu.render_frame(view, lights, w, h, max_depth=4)
+        floor = (c_hits["object"] == 0) & (o_hits["object"] == 0)
+        assert (floor & (c_rgb.sum(axis=1) > o_rgb.sum(axis=1))).sum() > 1000
+    finally:
+        gpu_ctx.set_option("traversal", 2)
+
+
+@pytest.mark.parametrize("traversal", TRAVERSALS)
 def test_many_instances_with_general_affine_transforms(gpu_ctx, traversal):
     """Twenty objects: two meshes instanced under rotated, sheared and mirrored transforms (Transform::from on an
     arbitrary forward matrix, src/geo/transform.rs:51-80), spheres, planes and a glass ball in between, so the object
