@@ -5,19 +5,33 @@ A step is one pass of the hot path over one batch: a full 1920x1080 primary-ray 
 BVH traversal + ray/triangle intersection + closest hit -> 16-byte hit records) against the 1 000 000-triangle
 terrain, inputs (scene, BVH) resident in HBM, outputs written to HBM.  With N > 1 every rank renders its own
 frame of the sequence (frame f -> rank f mod N, camera moved per frame; BVH replicated) and the hit buffers are
-gathered to rank 0 with RCCL inside the timed region, on a second stream so the gather of frame i overlaps the
-traversal of frame i+1 (two hit buffers per rank): weak scaling.  Every GPU keeps `--inflight` frames in flight
-(default 2: two contexts with a stream each take the frames in turn, sharing one uploaded tree), because the tail of
-a persistent launch -- its last rays finishing on a half-empty GPU -- is best hidden under the next frame's start.
+gathered to rank 0 inside the timed region by the library's own gather (rtg_gather_tiles: RCCL point-to-point
+transfers behind the C ABI), on a second stream so the gather of frame i overlaps the traversal of frame i+1 (two hit
+buffers per rank): weak scaling.  Every GPU keeps `--inflight` frames in flight (default 2: two contexts with a
+stream each take the frames in turn, sharing one uploaded tree), because the tail of a persistent launch -- its last
+rays finishing on a half-empty GPU -- is best hidden under the next frame's start.
+
+The timed region is `--windows` windows of exactly `--steps` steps, each bracketed by a barrier and a device
+synchronize on both sides; `value` / `ms_per_step` are the median window's, `windows_mrays` lists them all.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (k_trace_phased, the persistent traversal
-kernel behind rtg_render_primary) against HBM peak using ALGORITHMIC bytes (nodes visited x 64 B + triangles tested
-x 72 B + 16 B hit record per ray, counted by the kernel's counting build on the same frame) over the kernel's average
-launch duration from HIP events on the launching stream -- with two launches in flight a launch spans the time it
-shares the GPU with its neighbour, so `roofline.concurrent_launches` states how many overlap; `roofline.traffic` is
-the HBM traffic per launch from the rocprofv3 counter passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE),
-null when no committed pass matches the workload; `cpu_baseline` is the oracle (C++ restatement of the reference
-renderer, kind "port") timed on this host's cores on whole frames of the same sequence.
+kernel behind rtg_render_primary):
+  * the bound it is held against is the one that binds a tree that sits in the caches (config 2: 144 MB of nodes and
+    triangles inside the 256 MB Infinity Cache): the rate at which a CU's vector memory path serves gathered 16-byte
+    lane loads, measured by tools/micro/tcp_gather.hip per cache level and weighted by the kernel's own hit fractions
+    (profiles/<round>/ceiling.json, written by tools/roofline_ceiling.py from the committed microbenchmark output
+    and counter passes).  `achieved` = node visits per launch (counted by the kernel's counting build on the same
+    frame) / the launch's duration, `peak` = that ceiling, `frac` = achieved / peak;
+  * `traffic` is the HBM traffic per launch from the rocprofv3 counter passes committed under profiles/
+    (2 x FETCH_SIZE + WRITE_SIZE) and `hbm` the HBM roofline from it (traffic / duration against 8 TB/s);
+  * `algorithmic` is nodes visited x 64 B + triangles tested x 72 B + 16 B hit record per ray over the duration -- bytes
+    the traversal asks for, almost all served by L1/L2/Infinity Cache, so a figure above HBM peak is not a fraction
+    of anything and is reported for information only.
+The launch duration comes from HIP events that the launch itself fills with its execution window on the launching
+stream; with two launches in flight a launch spans the time it shares the GPU with its neighbour
+(`concurrent_launches`).  `configs.c4` is the same for configuration 4 (64 M incoherent rays against 10 M triangles,
+the HBM-resident case).  `cpu_baseline` is the oracle (C++ restatement of the reference renderer, kind "port") timed
+on this host's cores on whole frames of the same sequence.
 """
 import argparse
 import json
@@ -35,6 +49,9 @@ WIDTH, HEIGHT = 1920, 1080
 GRID = (1000, 500)             # quads -> 1 000 000 triangles
 SEED = 7
 LOCAL_SCALE = 100.0
+C4_GRID = (3163, 1581)         # quads -> 10 001 406 triangles
+C4_RAYS = 1 << 26
+C4_RAY_SEED = 10212233         # the reference benchmark's seed constant (src/tree/benchmark.rs:15)
 
 
 def frame_view(rtg, frame):
@@ -45,20 +62,100 @@ def frame_view(rtg, frame):
 KERNEL_OF_TRAVERSAL = {-1: "k_trace_phased", 0: "k_render_primary", 1: "k_render_primary", 2: "k_trace_phased"}
 
 
-def committed_traffic(workload_key, kernel):
-    """HBM bytes per launch of `kernel` from the newest committed counter summary for this workload, or None."""
+def committed(name, workload_key, kernel):
+    """The newest committed profiles/<dir>/<name stem>*.json for this workload and kernel, or None."""
     best = None
     prof = os.path.join(ROOT, "profiles")
     if not os.path.isdir(prof):
         return None
+    stem = name[:-len(".json")]
     for d in sorted(os.listdir(prof)):
-        path = os.path.join(prof, d, "traffic.json")
-        if os.path.isfile(path):
-            with open(path) as f:
+        if not os.path.isdir(os.path.join(prof, d)):
+            continue
+        for fn in sorted(os.listdir(os.path.join(prof, d))):
+            if not (fn.startswith(stem) and fn.endswith(".json")):
+                continue
+            with open(os.path.join(prof, d, fn)) as f:
                 t = json.load(f)
             if t.get("workload") == workload_key and t.get("kernel") == kernel:
+                t["file"] = os.path.join("profiles", d, fn)
                 best = t
-    return None if best is None else float(best["hbm_bytes_per_launch"])
+    return best
+
+
+def roofline_record(kernel, workload_key, kernel_ms, n_rays, nodes_per_ray, tris_per_ray, ray_in_bytes, use_committed):
+    """The `roofline` object.  Two ceilings are priced -- `gather` (the rate at which the CUs' vector memory path
+    serves the node fetches, per cache level) and `hbm` (counter traffic against HBM peak) -- and the top-level
+    bound / achieved / peak / frac are those of the one that binds (the larger fraction).  `algorithmic` is the byte
+    rate the traversal asks for, for information."""
+    seconds = kernel_ms * 1e-3
+    bytes_per_ray = nodes_per_ray * 64.0 + tris_per_ray * 72.0 + ray_in_bytes + 16.0
+    visits_per_s = nodes_per_ray * n_rays / seconds
+    ceiling = committed("ceiling.json", workload_key, kernel) if use_committed else None
+    traffic = committed("traffic.json", workload_key, kernel) if use_committed else None
+    gather = {"bound": "vector-memory gather rate (node fetches served by L1 / L2 / beyond)",
+              "achieved": round(visits_per_s / 1e9, 2), "peak": None, "unit": "G node visits/s", "frac": None}
+    if ceiling is not None:
+        gather["peak"] = round(ceiling["ceiling_visits_per_s"] / 1e9, 2)
+        gather["frac"] = round(visits_per_s / ceiling["ceiling_visits_per_s"], 4)
+        gather["source"] = ceiling["file"]
+    hbm = None
+    if traffic is not None:
+        b = float(traffic["hbm_bytes_per_launch"])
+        hbm = {"bound": "hbm", "achieved": round(b / seconds / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(b / seconds / 1e9 / HBM_PEAK_GBS, 4), "source": traffic["file"]}
+    binding = hbm if (hbm is not None and (gather["frac"] is None or hbm["frac"] > gather["frac"])) else gather
+    rec = {k: binding[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+    rec.update({"traffic": None if traffic is None else round(float(traffic["hbm_bytes_per_launch"]) / 1e9, 4),
+                "traffic_unit": "GB per launch", "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
+                "nodes_per_ray": round(float(nodes_per_ray), 2), "tris_per_ray": round(float(tris_per_ray), 2),
+                "gather": gather, "hbm": hbm,
+                "algorithmic": {"bytes_per_ray": round(bytes_per_ray, 1),
+                                "gbs": round(bytes_per_ray * n_rays / seconds / 1e9, 1),
+                                "note": "bytes the traversal asks for; mostly cache hits, not HBM traffic"}})
+    return rec
+
+
+def run_config4(rtg, torch, ctx, dev, launches=3):
+    """Configuration 4 on one GPU: 67 108 864 `bench_mesh` rays against the 10 001 406-triangle tree (built on the
+    GPU), hit records only.  Returns the `configs.c4` record."""
+    t0 = time.time()
+    tris = rtg.heightfield(C4_GRID[0], C4_GRID[1], SEED, 1.0)
+    mesh = ctx.build_mesh(tris)
+    n_nodes, n_leaves, _, depth = mesh.sizes()
+    scene = ctx.scene([rtg.mesh_object(mesh, rtg.material((1, 1, 1)), rtg.transform())])
+    rays = rtg.bench_mesh_rays(mesh.bounds(), C4_RAYS, seed=C4_RAY_SEED)
+    d_rays = torch.from_numpy(rays).to(dev)
+    del rays
+    hits = torch.empty(C4_RAYS * 16, dtype=torch.uint8, device=dev)
+    ctr = torch.empty(C4_RAYS * 2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    setup_s = time.time() - t0
+    scene.trace_raw(d_rays.data_ptr(), C4_RAYS, hits.data_ptr(), None, ctr.data_ptr())
+    ctx.synchronize()
+    c = ctr.view(C4_RAYS, 2).to(torch.int64).sum(dim=0).cpu().numpy()
+    del ctr
+    ctx.set_option("time_kernels", 2)
+    ctx.kernel_time()
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        scene.trace_raw(d_rays.data_ptr(), C4_RAYS, hits.data_ptr())
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    ms, n = ctx.kernel_time()
+    ctx.set_option("time_kernels", 1)
+    assert n == launches
+    kernel_ms = ms / launches
+    n_hit = int((hits.view(torch.int32).view(C4_RAYS, 4)[:, 1] != -1).sum().item())
+    rec = {"workload": f"config 4: {C4_RAYS} bench_mesh rays (seed {C4_RAY_SEED}) vs {n_leaves}-triangle BVH "
+                       f"({n_nodes} nodes, depth {depth}, built on the GPU), closest-hit ids",
+           "value": round(C4_RAYS * launches / wall / 1e6, 1), "unit": "Mrays/s", "launches": launches,
+           "ms_per_launch": round(wall / launches * 1e3, 3), "rays_hit": n_hit, "setup_s": round(setup_s, 2),
+           "roofline": roofline_record("k_trace_phased", "config4-64Mrays-10Mtris", kernel_ms, C4_RAYS,
+                                       c[0] / C4_RAYS, c[1] / C4_RAYS, 48.0, True)}
+    scene.close()
+    mesh.close()
+    return rec
 
 
 def main():
@@ -66,14 +163,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the median is reported")
     ap.add_argument("--traversal", type=int, default=-1, help="0 short stack, 1 threaded, 2 phased threaded, -1 library default")
     ap.add_argument("--opt", action="append", default=[], help="ctx option key=value (e.g. tri_min=16)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-c4", action="store_true", help="skip the configuration 4 record")
     ap.add_argument("--grid", type=str, default=None, help="NXxNY quads (default 1000x500)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="frames in flight per GPU: that many contexts (one stream each) take the frames in turn")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the gather path even with one rank (rehearses the multi-GPU step on a 1-GPU box)")
+    ap.add_argument("--gather", choices=["native", "torch"], default="native",
+                    help="native: rtg_gather_tiles behind the C ABI (RCCL send/recv); torch: torch.distributed.gather")
     args = ap.parse_args()
 
     import torch
@@ -119,9 +220,9 @@ def main():
         if args.traversal >= 0:
             c.set_option("traversal", args.traversal)
         if use_dist:
-            # The persistent kernel fills every block slot of the GPU for the whole frame (128 VGPRs x 4 waves per
-            # SIMD), so a gather kernel on the second stream could only start when a frame drains.  Leaving 32 of
-            # the 1024 slots free lets RCCL's send/recv blocks run next to the traversal of the following frame.
+            # The persistent kernel fills every block slot of the GPU for the whole frame, so a gather kernel on the
+            # second stream could only start when a frame drains.  Leaving 32 of the 1024 four-wave slots free lets
+            # RCCL's send/recv blocks run next to the traversal of the following frame.
             c.set_option("max_blocks", 992)
         for kv in args.opt:
             k, v = kv.split("=")
@@ -139,16 +240,45 @@ def main():
 
     n_rays = WIDTH * HEIGHT
     tile = (0, 0, WIDTH, HEIGHT)
+    frame_bytes = n_rays * 16
     n_buf = 2 if use_dist else 1
-    hits_of = [[torch.empty(n_rays * 16, dtype=torch.uint8, device=dev) for _ in range(n_buf)] for _ in range(inflight)]
+    hits_of = [[torch.empty(frame_bytes, dtype=torch.uint8, device=dev) for _ in range(n_buf)] for _ in range(inflight)]
     hits = hits_of[0][0]
     sizes = [hits.numel()] * world
+    gather_kind = None
     if use_dist:
-        comm = torch.cuda.Stream(dev)                 # gathers run here, traversal on the contexts' streams
-        recv = [[[torch.empty_like(hits) for _ in range(world)] if rank == 0 else None for _ in range(2)]
-                for _ in range(inflight)]
+        comm_stream = torch.cuda.Stream(dev)          # gathers run here, traversal on the contexts' streams
         rendered = [[torch.cuda.Event() for _ in range(2)] for _ in range(inflight)]
         gathered = [[torch.cuda.Event() for _ in range(2)] for _ in range(inflight)]
+        comm = None
+        if args.gather == "native":
+            # the library's own communicator: rank 0 makes the id, the others get it over the process group
+            try:
+                uid = torch.zeros(rtg.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+                if rank == 0 and world > 1:
+                    uid.copy_(torch.frombuffer(bytearray(rtg.comm_unique_id()), dtype=torch.uint8))
+                if world > 1:
+                    dist.broadcast(uid, src=0)
+                comm = rtg.Comm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()) if world > 1 else None)
+                gather_kind = "rtg_gather_tiles (RCCL send/recv behind the C ABI)"
+            except Exception as e:                    # noqa: BLE001 -- reported in the JSON line, not hidden
+                gather_kind = f"torch.distributed.gather (rtg_comm_create failed: {e})"
+            if world > 1:                             # every rank must take the same path
+                ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and comm is not None:
+                    comm.close()
+                    comm = None
+                    gather_kind = "torch.distributed.gather (rtg_comm_create failed on another rank)"
+        else:
+            gather_kind = "torch.distributed.gather"
+        pieces = shard.frame_pieces(world, frame_bytes)
+        if comm is not None:
+            recv = [[torch.empty(world * frame_bytes, dtype=torch.uint8, device=dev) if rank == 0 else None
+                     for _ in range(2)] for _ in range(inflight)]
+        else:
+            recv = [[[torch.empty_like(hits) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+                    for _ in range(inflight)]
 
     def step(i, ev=None):
         frame = i * world + rank
@@ -164,10 +294,14 @@ def main():
             ev[1].record(st)
         if use_dist:
             rendered[k][b].record(st)
-            comm.wait_event(rendered[k][b])
-            with torch.cuda.stream(comm):             # RCCL gather of the finished framebuffers to rank 0
-                shard.gather_to_root(hits_of[k][b], sizes, dst=0, out=recv[k][b])
-                gathered[k][b].record(comm)
+            comm_stream.wait_event(rendered[k][b])
+            if comm is not None:                      # gather of the finished framebuffers to rank 0
+                comm.gather(0, hits_of[k][b].data_ptr(), recv[k][b].data_ptr() if rank == 0 else None, pieces,
+                            stream_handle=comm_stream.cuda_stream)
+            else:
+                with torch.cuda.stream(comm_stream):
+                    shard.gather_to_root(hits_of[k][b], sizes, dst=0, out=recv[k][b])
+            gathered[k][b].record(comm_stream)
 
     for i in range(args.warmup):
         step(i)
@@ -175,45 +309,54 @@ def main():
     # (the dispatch's own begin and end timestamps -- what rocprofv3 reports per dispatch).  Events recorded around the call
     # would also count the time a launch waits in its stream's queue while the previous frame still owns the GPU.
     timed_kernels = args.traversal in (-1, 2)
-    if timed_kernels:
+    n_windows = max(1, args.windows)
+    window_s, window_kernel_ms = [], []
+    done = args.warmup
+    for w_ in range(n_windows):
+        if timed_kernels:
+            torch.cuda.synchronize(dev)
+            for c in ctxs:
+                c.set_option("time_kernels", 2)
+                c.kernel_time()
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        if use_dist:
+            dist.barrier()
         torch.cuda.synchronize(dev)
-        for c in ctxs:
-            c.set_option("time_kernels", 2)
-            c.kernel_time()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, events[i])
-    torch.cuda.synchronize(dev)                       # both streams: every frame rendered and gathered
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
-    if timed_kernels:
-        windows = [c.kernel_time() for c in ctxs]
-        for c in ctxs:
-            c.set_option("time_kernels", 1)
-        assert sum(n for _, n in windows) == args.steps
-        kernel_ms = sum(ms for ms, _ in windows) / args.steps
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(done + i, events[i])
+        torch.cuda.synchronize(dev)                   # every stream: every frame rendered and gathered
+        if use_dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        done += args.steps
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        if timed_kernels:
+            windows = [c.kernel_time() for c in ctxs]
+            for c in ctxs:
+                c.set_option("time_kernels", 1)
+            assert sum(n for _, n in windows) == args.steps
+            kernel_ms = sum(ms for ms, _ in windows) / args.steps
+        window_s.append(elapsed)
+        window_kernel_ms.append(kernel_ms)
+    order = np.argsort(window_s)
+    mid = int(order[(n_windows - 1) // 2])            # the median window (the lower one of an even count)
+    elapsed, kernel_ms = window_s[mid], window_kernel_ms[mid]
 
     if rank == 0:
-        # algorithmic bytes of one launch, from the kernel's own counting build on frame 0
+        # node visits and algorithmic bytes of one launch, from the kernel's own counting build on frame 0
         ctr = torch.empty(n_rays * 2, dtype=torch.int32, device=dev)
         scene.render_primary_raw(frame_view(rtg, 0), WIDTH, HEIGHT, tile, hits.data_ptr(), None, ctr.data_ptr())
         torch.cuda.synchronize(dev)
         c = ctr.view(n_rays, 2).to(torch.int64).sum(dim=0).cpu().numpy()
+        del ctr
         nodes_per_ray, tris_per_ray = c[0] / n_rays, c[1] / n_rays
-        bytes_per_ray = nodes_per_ray * 64.0 + tris_per_ray * 72.0 + 0.0 + 16.0
-        alg_bytes = bytes_per_ray * n_rays
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         mrays = args.steps * world * n_rays / elapsed / 1e6
+        window_mrays = [round(args.steps * world * n_rays / s / 1e6, 1) for s in window_s]
 
         cpu = None
         if not args.no_cpu and world == 1:          # the CPU leg is reported for the single-GPU line only
@@ -243,24 +386,32 @@ def main():
 
         kernel = KERNEL_OF_TRAVERSAL[args.traversal]
         default_run = args.traversal < 0 and not args.opt and args.grid is None
-        traffic = committed_traffic("config2-1920x1080", kernel) if default_run else None
+        roof = roofline_record(kernel, "config2-1920x1080", kernel_ms, n_rays, nodes_per_ray, tris_per_ray, 0.0, default_run)
+        roof["concurrent_launches"] = inflight
+        # the same visits against the whole timed region: what the GPU sustains with `inflight` launches overlapping
+        roof["gather"]["achieved_timed_region"] = round(nodes_per_ray * n_rays * args.steps / elapsed / 1e9, 2)
+        if roof["gather"]["peak"]:
+            roof["gather"]["frac_timed_region"] = round(roof["gather"]["achieved_timed_region"] / roof["gather"]["peak"], 4)
+        configs = None
+        if world == 1 and not args.no_c4 and default_run:
+            torch.cuda.set_stream(stream)
+            configs = {"c4": run_config4(rtg, torch, ctx, dev)}
         out = {
             "metric": "Mrays/s, 1M-tri BVH scene", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "windows": n_windows, "windows_mrays": window_mrays,
+            "spread": round((max(window_mrays) - min(window_mrays)) / float(np.median(window_mrays)), 4),
             "config": {"workload": f"config 2: {2 * nx * ny}-triangle terrain BVH ({bvh.n_nodes} nodes, depth {bvh.depth}), "
                                    f"{WIDTH}x{HEIGHT} primary rays per step per GPU, closest-hit ids",
                        "traversal": "library default" if args.traversal < 0 else ["short-stack", "threaded", "phased-threaded"][args.traversal],
                        "parallelism": f"frames sharded over {world} GPU(s), BVH replicated"
-                                      + (", RCCL gather to rank 0 overlapped with the next frame" if use_dist else "")
+                                      + (f", gather to rank 0 by {gather_kind}, overlapped with the next frame" if use_dist else "")
                                       + f", {inflight} frame(s) in flight per GPU",
                        "host_bvh_build_s": round(build_s, 2)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if traffic is None else round(traffic / 1e9, 4), "traffic_unit": "GB per launch",
-                         "kernel": kernel, "concurrent_launches": inflight,
-                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
-                         "nodes_per_ray": round(float(nodes_per_ray), 2), "tris_per_ray": round(float(tris_per_ray), 2)},
+            "roofline": roof,
             "cpu_baseline": cpu,
+            "configs": configs,
         }
         print(json.dumps(out), file=json_out, flush=True)
     if use_dist:

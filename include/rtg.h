@@ -344,6 +344,42 @@ int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *li
                      uint32_t n_lights, uint32_t width, uint32_t height, rtg_rect tile,
                      uint32_t max_depth, double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits);
 
+/* ---- several GPUs ----------------------------------------------------- */
+
+/* The path has no exchange during compute: the scene is replicated and pixels / frames are independent
+ * (src/render/renderer.rs:147-149 maps over `&self`; the reference itself fans frames out to HTTP workers and
+ * collects their tar files, scripts/request_all.sh:2, src/bin/server.rs:19-33).  One process (or host thread) and
+ * one rtg_ctx per GPU; the only data that moves is finished output, gathered to one GPU per frame with RCCL
+ * point-to-point transfers over xGMI.  RCCL is bound at run time; a one-rank communicator needs none. */
+typedef struct rtg_comm rtg_comm;
+#define RTG_COMM_ID_BYTES 128
+/* Rank 0 makes the id (RCCL's unique id) and hands it to the other ranks by any channel the host has. */
+int rtg_comm_unique_id(uint8_t id[RTG_COMM_ID_BYTES]);
+/* Collective over the n_ranks callers; `id` may be NULL when n_ranks is 1.  The communicator belongs to `ctx`'s GPU
+ * and must be destroyed before the context. */
+int rtg_comm_create(rtg_ctx *ctx, const uint8_t id[RTG_COMM_ID_BYTES], int n_ranks, int rank, rtg_comm **out);
+/* Wraps an ncclComm_t the host already has (not destroyed by rtg_comm_destroy). */
+int rtg_comm_adopt(rtg_ctx *ctx, void *nccl_comm, int n_ranks, int rank, rtg_comm **out);
+void rtg_comm_destroy(rtg_comm *comm);
+
+/* One piece of a gathered frame: `bytes` bytes that rank `rank` holds at `send_offset` of its send buffer and that
+ * land at `recv_offset` of the root's receive buffer (a full-width strip of rows lands where it sits in the frame,
+ * so the gather assembles the image). */
+typedef struct {
+    uint32_t rank;
+    uint32_t _pad;
+    uint64_t send_offset;
+    uint64_t recv_offset;
+    uint64_t bytes;
+} rtg_piece;
+
+/* Gathers finished output to rank `root`: replaces collecting the workers' responses (scripts/request_all.sh:2).
+ * Every rank passes the same piece list; a rank sends its own pieces in list order, the root receives them in
+ * list order and copies its own pieces on the device.  `send` / `recv` are device memory (`recv` is only read on
+ * the root).  Enqueued on `hip_stream` (NULL: the context's stream), so it overlaps work on other streams. */
+int rtg_gather_tiles(rtg_comm *comm, int root, const void *send, void *recv, const rtg_piece *pieces,
+                     uint32_t n_pieces, void *hip_stream);
+
 /* Library build info: "rtg <version> gfx950". */
 const char *rtg_version(void);
 

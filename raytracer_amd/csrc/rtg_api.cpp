@@ -20,72 +20,31 @@
 #include <thread>
 #include <vector>
 
+#include "rtg_internal.hpp"
 #include "rtg_launch.hpp"
 
 using namespace rtg;
 
 namespace {
 thread_local std::string g_create_error;
-
-struct DeviceBuffer {
-    void *ptr = nullptr;
-    size_t bytes = 0;
-};
+using DeviceBuffer = RtgDeviceBuffer;
 } // namespace
-
-struct rtg_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    int traversal = 2;
-    PhasedTuning tune;
-    std::string err;
-    std::map<std::string, DeviceBuffer> scratch;
-    // option "time_kernels": execution windows of the persistent kernel launches behind rtg_render_primary and
-    // rtg_trace, summed by rtg_ctx_kernel_time
-    bool time_kernels = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, idle_events;
-    // rtg_render_frame renders a frame of an opaque scene as two row bands on two streams (option "frame_bands"):
-    // `side` is an internal context (own stream and scratch) for the second band, joined back by events
-    uint32_t frame_bands = 2;
-    rtg_ctx *side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-};
-
-struct rtg_mesh {
-    int device = 0;                  // a mesh may outlive the context that made it: only the GPU is remembered
-    DevMesh dev{};
-    void *d_nodes = nullptr, *d_slab = nullptr, *d_normals = nullptr;
-    void *d_patches = nullptr, *d_leaf_info = nullptr;
-    void *d_leaf_source = nullptr;   // built on the device: the caller's triangle index of every leaf
-    bool is_patches = false;
-    double bounds[6] = {0, 0, 0, 0, 0, 0};
-    uint64_t n_leaves = 0;
-};
-
-struct rtg_scene {
-    rtg_ctx *ctx = nullptr;          // calls on the scene run on this context: it must outlive the scene's last call
-    int device = 0;                  // rtg_scene_destroy only needs the GPU
-    DevScene dev{};
-    void *d_objects = nullptr, *d_mesh_objects = nullptr;
-    uint32_t max_depth = 0;
-    bool any_dielectric = false;   // some material refracts: frames need the specular path tree
-    bool has_mesh = false;         // some object is a mesh or patch set: shading is worth doing as passes of the
-                                   // persistent kernel (sphere/plane-only scenes are cheaper in one fused launch)
-};
 
 namespace {
 
+void set_error(rtg_ctx *ctx, const char *text) {
+    if (ctx)
+        ctx->err = text;
+    else
+        g_create_error = text;
+}
 int fail(rtg_ctx *ctx, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (ctx)
-        ctx->err = buf;
-    else
-        g_create_error = buf;
+    set_error(ctx, buf);
     return code;
 }
 
@@ -395,6 +354,19 @@ int scene_for_launch(rtg_scene *scene, uint64_t threads, DevScene &out) {
 }
 
 } // namespace
+
+namespace rtg {
+int api_fail(rtg_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    set_error(ctx, buf);
+    return code;
+}
+bool api_is_device_pointer(const void *p) { return is_device_pointer(p); }
+} // namespace rtg
 
 extern "C" {
 

@@ -77,6 +77,14 @@ class Rect(C.Structure):
     _fields_ = [("x0", C.c_uint32), ("y0", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32)]
 
 
+class Piece(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("_pad", C.c_uint32), ("send_offset", C.c_uint64), ("recv_offset", C.c_uint64),
+                ("bytes", C.c_uint64)]
+
+
+COMM_ID_BYTES = 128
+
+
 NODE_DTYPE = np.dtype([("lo", "<f8", 3), ("hi", "<f8", 3), ("child_begin", "<u4"), ("child_end", "<u4"),
                        ("leaf_begin", "<u4"), ("leaf_end", "<u4")])
 HIT_DTYPE = np.dtype([("object", "<u4"), ("leaf", "<u4"), ("t", "<f8")])
@@ -133,6 +141,12 @@ _sig(lib.rtg_trace_paths, C.c_int, _vp, _vp, C.c_uint64, C.c_uint32, _vp, C.c_ui
 _sig(lib.rtg_shade_direct, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, _vp, _vp)
 _sig(lib.rtg_render_frame, C.c_int, _vp, C.POINTER(View), _vp, C.c_uint32, C.c_uint32, C.c_uint32, Rect,
      C.c_uint32, _vp, _vp, _vp)
+
+_sig(lib.rtg_comm_unique_id, C.c_int, _vp)
+_sig(lib.rtg_comm_create, C.c_int, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp))
+_sig(lib.rtg_comm_adopt, C.c_int, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp))
+_sig(lib.rtg_comm_destroy, None, _vp)
+_sig(lib.rtg_gather_tiles, C.c_int, _vp, C.c_int, _vp, _vp, C.POINTER(Piece), C.c_uint32, _vp)
 
 _sig(host.rth_bvh_build_subdivide, _vp, _vp, C.c_uint64, _vp, C.c_int)
 _sig(host.rth_bvh_build, _vp, _vp, C.c_uint64, _vp, C.c_int, C.c_int)
@@ -390,6 +404,7 @@ class Context:
         self._h = h
         self.device = device
         self._scenes = weakref.WeakSet()      # scenes run on their context: they are closed before it
+        self._comms = weakref.WeakSet()       # so are communicators
 
     def _check(self, rc):
         if rc != 0:
@@ -441,7 +456,7 @@ class Context:
 
     def close(self):
         if self._h:
-            for sc in list(self._scenes):
+            for sc in list(self._scenes) + list(self._comms):
                 sc.close()
             lib.rtg_ctx_destroy(self._h)
             self._h = None
@@ -450,6 +465,49 @@ class Context:
         try:
             self.close()
         except Exception:      # interpreter shutdown: the library globals may already be gone
+            pass
+
+
+def comm_unique_id():
+    """RCCL unique id (bytes) made by one rank and handed to the others."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = lib.rtg_comm_unique_id(buf)
+    if rc != 0:
+        raise RtgError(rc, lib.rtg_last_error(None).decode())
+    return bytes(buf)
+
+
+class Comm:
+    """The ranks that gather finished output (one per GPU); a one-rank communicator needs no id and no RCCL."""
+    _h = None
+
+    def __init__(self, ctx, n_ranks=1, rank=0, unique_id=None):
+        h = _vp()
+        idbuf = None
+        if unique_id is not None:
+            assert len(unique_id) == COMM_ID_BYTES
+            idbuf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        ctx._check(lib.rtg_comm_create(ctx._h, idbuf, n_ranks, rank, C.byref(h)))
+        self._h, self.ctx, self.n_ranks, self.rank = h, ctx, n_ranks, rank
+        ctx._comms.add(self)
+
+    def gather(self, root, send_ptr, recv_ptr, pieces, stream_handle=None):
+        """pieces: [(rank, send_offset, recv_offset, bytes)], the same list on every rank."""
+        arr = (Piece * max(1, len(pieces)))()
+        for i, (r, so, ro, nb) in enumerate(pieces):
+            arr[i].rank, arr[i].send_offset, arr[i].recv_offset, arr[i].bytes = r, so, ro, nb
+        self.ctx._check(lib.rtg_gather_tiles(self._h, root, _ptr(send_ptr), _ptr(recv_ptr), arr, len(pieces),
+                                             C.c_void_p(stream_handle) if stream_handle else None))
+
+    def close(self):
+        if self._h:
+            lib.rtg_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown
             pass
 
 

@@ -51,6 +51,26 @@ def rect_pixels(rects: Sequence[Rect]) -> int:
     return sum(w * h for _, _, w, h in rects)
 
 
+def strip_pieces(plan: Sequence[Sequence[Rect]], width: int, pixel_bytes: int):
+    """Piece list for rtg_gather_tiles from a tile_strips plan: every rank keeps its strips back to back in its send
+    buffer (plan order) and a full-width strip lands at its rows of the frame, so the gather assembles the image.
+    Returns [(rank, send_offset, recv_offset, bytes)]."""
+    pieces = []
+    for rank, rects in enumerate(plan):
+        off = 0
+        for x0, y0, w, h in rects:
+            assert x0 == 0 and w == width, "strips are full-width"
+            nb = w * h * pixel_bytes
+            pieces.append((rank, off, y0 * width * pixel_bytes, nb))
+            off += nb
+    return pieces
+
+
+def frame_pieces(world: int, frame_bytes: int, live=None):
+    """Piece list of frame mode: rank r's finished frame lands in slot r of the root's receive buffer."""
+    return [(r, 0, r * frame_bytes, frame_bytes) for r in range(world) if live is None or live[r]]
+
+
 def gather_to_root(local: torch.Tensor, sizes: Sequence[int], dst: int = 0, group=None, out=None):
     """Gathers each rank's flat buffer (`sizes[r]` elements on rank r) to rank `dst`.
     Equal sizes use one `gather` collective; unequal sizes use grouped point-to-point sends, which is what RCCL
@@ -84,58 +104,81 @@ def gather_to_root(local: torch.Tensor, sizes: Sequence[int], dst: int = 0, grou
     return bufs
 
 
-def assemble_frame(width: int, height: int, rects_per_rank: Sequence[Sequence[Rect]], buffers: Sequence[torch.Tensor],
-                   channels: int) -> torch.Tensor:
-    """Places every rank's strips (concatenated in rect order, `channels` elements per pixel) into a
-    (height, width, channels) frame."""
-    frame = torch.empty((height, width, channels), dtype=buffers[0].dtype, device=buffers[0].device)
-    for rects, buf in zip(rects_per_rank, buffers):
-        off = 0
-        for x0, y0, w, h in rects:
-            n = w * h * channels
-            frame[y0:y0 + h, x0:x0 + w, :] = buf[off:off + n].view(h, w, channels)
-            off += n
-        assert off == buf.numel()
-    return frame
+def gather_pieces(send: torch.Tensor, recv, pieces, dst: int = 0, group=None):
+    """The protocol of rtg_gather_tiles over `torch.distributed` point-to-point operations (gloo on CPUs): every rank
+    passes the same piece list [(rank, send_offset, recv_offset, bytes)] over flat uint8 tensors; a rank sends its
+    own pieces in list order, `dst` receives them in list order straight into `recv` and copies its own pieces.
+    The stand-in for the native gather where there is no GPU, and the check that a piece plan assembles the frame."""
+    rank = dist.get_rank(group)
+    ops = []
+    for r, so, ro, nb in pieces:
+        if nb == 0:
+            continue
+        if rank == dst:
+            if r == dst:
+                recv[ro:ro + nb].copy_(send[so:so + nb])
+            else:
+                ops.append(dist.P2POp(dist.irecv, recv[ro:ro + nb], r, group))
+        elif r == rank:
+            ops.append(dist.P2POp(dist.isend, send[so:so + nb], dst, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
 
 
 def render_frame_tiles(render_rect, width: int, height: int, channels: int, dtype, device, interleave: int = 4,
-                       dst: int = 0, group=None):
-    """Tile mode: this rank renders its strips with `render_rect(rect, out_flat_tensor)` and the strips are gathered
-    on `dst`, which returns the assembled (height, width, channels) frame; other ranks return None."""
+                       dst: int = 0, group=None, gather=None):
+    """Tile mode: this rank renders its strips with `render_rect(rect, out_flat_tensor)` back to back into its send
+    buffer; one gather lands every strip at its rows of the frame on `dst`, which returns the (height, width,
+    channels) frame; other ranks return None.  `gather(send_bytes, recv_bytes_or_None, pieces)` moves the pieces
+    (default: gather_pieces over torch.distributed; GPU callers pass rtg.Comm.gather on device addresses)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     plan = tile_strips(width, height, world, interleave)
-    sizes = [rect_pixels(r) * channels for r in plan]
-    local = torch.empty(sizes[rank], dtype=dtype, device=device)
+    item = torch.empty((), dtype=dtype).element_size()
+    pieces = strip_pieces(plan, width, channels * item)
+    local = torch.empty(rect_pixels(plan[rank]) * channels, dtype=dtype, device=device)
     off = 0
     for rect in plan[rank]:
         n = rect[2] * rect[3] * channels
         render_rect(rect, local[off:off + n])
         off += n
-    bufs = gather_to_root(local, sizes, dst, group)
-    if rank != dst:
-        return None
-    return assemble_frame(width, height, plan, bufs, channels)
+    frame = torch.empty((height, width, channels), dtype=dtype, device=device) if rank == dst else None
+    send_b = local.view(torch.uint8)
+    recv_b = frame.view(-1).view(torch.uint8) if frame is not None else None
+    if gather is None:
+        gather_pieces(send_b, recv_b, pieces, dst, group)
+    else:
+        gather(send_b, recv_b, pieces)
+    return frame
 
 
-def render_sequence_frames(render_frame, n_frames: int, frame_elems: int, dtype, device, dst: int = 0, group=None):
-    """Frame mode: rank r renders frames r, r+world, ...; after each round the `world` frames are gathered on `dst`.
-    `render_frame(frame_index, out_flat_tensor)`.  Returns {frame index: tensor} on `dst`, None elsewhere."""
+def render_sequence_frames(render_frame, n_frames: int, frame_elems: int, dtype, device, dst: int = 0, group=None,
+                           gather=None):
+    """Frame mode: rank r renders frames r, r+world, ...; after each round the `world` frames are gathered on `dst`
+    (rank r's frame into slot r of the receive buffer).  `render_frame(frame_index, out_flat_tensor)`; `gather` as in
+    render_frame_tiles.  Returns {frame index: tensor} on `dst`, None elsewhere."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     out = {} if rank == dst else None
     local = torch.empty(frame_elems, dtype=dtype, device=device)
+    slots = torch.empty((world, frame_elems), dtype=dtype, device=device) if rank == dst else None
+    frame_bytes = frame_elems * local.element_size()
     for base in range(0, n_frames, world):
-        f = base + rank
         live = [base + r < n_frames for r in range(world)]
         if live[rank]:
-            render_frame(f, local)
-        sizes = [frame_elems if live[r] else 0 for r in range(world)]
-        mine = local if live[rank] else local[:0]
-        bufs = gather_to_root(mine, sizes, dst, group)
+            render_frame(base + rank, local)
+        pieces = frame_pieces(world, frame_bytes, live)
+        send_b = local.view(torch.uint8)
+        recv_b = slots.view(-1).view(torch.uint8) if slots is not None else None
+        if gather is None:
+            gather_pieces(send_b, recv_b, pieces, dst, group)
+        else:
+            gather(send_b, recv_b, pieces)
         if rank == dst:
+            if gather is not None and device != "cpu":
+                torch.cuda.synchronize()
             for r in range(world):
                 if live[r]:
-                    out[base + r] = bufs[r].clone()
+                    out[base + r] = slots[r].clone()
     return out

@@ -1,0 +1,50 @@
+"""GPU: rtg_gather_tiles with one rank (the gather degenerates to device copies on the stream; no RCCL needed), and
+the piece plans of frame and tile mode.  The multi-rank partition itself is covered on CPUs in test_shard_gloo.py."""
+import numpy as np
+import pytest
+
+import scenes
+from raytracer_amd import rtg, shard
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_rank_gather_assembles_the_frame_from_strips(gpu_ctx):
+    import torch
+    tris, xform = scenes.terrain(50, 50, seed=5)
+    mesh = gpu_ctx.mesh(rtg.HostBvh(tris))
+    scene = gpu_ctx.scene([rtg.mesh_object(mesh, rtg.material((1, 1, 1)), xform)])
+    view = rtg.make_view()
+    w, h = 328, 203
+    whole = torch.empty(w * h * 16, dtype=torch.uint8, device="cuda")
+    scene.render_primary_raw(view, w, h, (0, 0, w, h), whole.data_ptr())
+    # tile mode with one rank: the strips are rendered back to back into a send buffer in plan order ...
+    plan = shard.tile_strips(w, h, world=1, interleave=5)
+    pieces = shard.strip_pieces(plan, w, 16)
+    assert sum(p[3] for p in pieces) == w * h * 16 and len(pieces) == 5
+    send = torch.empty(w * h * 16, dtype=torch.uint8, device="cuda")
+    for (x0, y0, tw, th), (_, so, _, nb) in zip(plan[0], pieces):
+        scene.render_primary_raw(view, w, h, (x0, y0, tw, th), send.data_ptr() + so)
+        assert nb == tw * th * 16
+    # ... and gathered in a shuffled piece order into a poisoned frame
+    recv = torch.full((w * h * 16,), 0x5A, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    comm = rtg.Comm(gpu_ctx)
+    comm.gather(0, send.data_ptr(), recv.data_ptr(), pieces[::-1])
+    gpu_ctx.synchronize()
+    assert recv.cpu().numpy().tobytes() == whole.cpu().numpy().tobytes()
+    # a caller's stream is honoured
+    st = torch.cuda.Stream()
+    recv.fill_(0)
+    torch.cuda.synchronize()
+    comm.gather(0, send.data_ptr(), recv.data_ptr(), pieces, stream_handle=st.cuda_stream)
+    st.synchronize()
+    assert recv.cpu().numpy().tobytes() == whole.cpu().numpy().tobytes()
+    # in-place pieces (send already sits where it lands) are left alone
+    comm.gather(0, whole.data_ptr(), whole.data_ptr(), [(0, 0, 0, w * h * 16)])
+    with pytest.raises(rtg.RtgError, match="rank 1 of 1"):
+        comm.gather(0, send.data_ptr(), recv.data_ptr(), [(1, 0, 0, 16)])
+    with pytest.raises(rtg.RtgError, match="device memory"):
+        comm.gather(0, np.zeros(16, np.uint8), recv.data_ptr(), [(0, 0, 0, 16)])
+    comm.close()
+    scene.close()

@@ -33,6 +33,22 @@ def test_tile_strips_cover_the_frame_once():
     assert shard.frames_of_rank(1, 4, 10) == [1, 5, 9] and shard.frame_owner(9, 4) == 1
 
 
+def test_piece_plans_tile_the_receive_buffer_once():
+    for (w, h, world, inter, px) in [(64, 64, 2, 4, 16), (1920, 1080, 8, 4, 4), (33, 7, 4, 2, 16), (100, 1000, 3, 1, 1)]:
+        plan = shard.tile_strips(w, h, world, inter)
+        pieces = shard.strip_pieces(plan, w, px)
+        cover = np.zeros(w * h * px, dtype=np.int32)
+        sent = [0] * world
+        for r, so, ro, nb in pieces:
+            assert so == sent[r]                       # a rank's pieces sit back to back in its send buffer
+            sent[r] += nb
+            cover[ro:ro + nb] += 1
+        assert (cover == 1).all()
+        assert sent == [shard.rect_pixels(rects) * px for rects in plan]
+    assert shard.frame_pieces(3, 10) == [(0, 0, 0, 10), (1, 0, 10, 10), (2, 0, 20, 10)]
+    assert shard.frame_pieces(3, 10, live=[True, False, True]) == [(0, 0, 0, 10), (2, 0, 20, 10)]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

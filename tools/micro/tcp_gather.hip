@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 4) void k_gather(const vu4 *__restrict__ recs,
 }
 
 int main() {
-    const uint32_t n_max = 2u << 20;   // 2M records x 32 B = 64 MB
+    const uint32_t n_max = 32u << 20;  // 32M records x 32 B = 1 GB
     std::vector<uint32_t> h((size_t)n_max * 8);
     for (size_t i = 0; i < h.size(); i++) h[i] = (uint32_t)(i * 2654435761u);
     vu4 *d;
@@ -62,8 +62,8 @@ int main() {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    const uint32_t sizes[3] = {256u, 65536u, 2u << 20};   // 8 KB (L1), 2 MB (L2), 64 MB (MALL)
-    for (int si = 0; si < 3; si++)
+    const uint32_t sizes[4] = {256u, 65536u, 2u << 20, 32u << 20};   // 8 KB (L1), 2 MB (L2), 64 MB (MALL), 1 GB (HBM)
+    for (int si = 0; si < 4; si++)
     for (int mode = 0; mode < 5; mode++) {
         const uint32_t n_recs = sizes[si];
         for (int rep = 0; rep < 2; rep++) {
