@@ -311,6 +311,18 @@ int rtg_render_primary(rtg_scene *scene, const rtg_view *view, uint32_t width, u
                        rtg_rect tile, rtg_hit *out_hits, rtg_point *out_points,
                        rtg_ray_counters *out_counters);
 
+/* rtg_render_primary for callers that cannot allocate.  It has no counterpart in the reference; it is for callers
+ * that cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same hit ids and times as rtg_render_primary, with these differences: `out_hits` must be device memory on the
+ * scene's GPU (16-byte aligned); the tile may hold at most RTG_STATIC_MAX_PIXELS pixels (RTG_E_LIMIT beyond);
+ * always the default (persistent) traversal; the call neither allocates nor frees device or host memory and is
+ * asynchronous on the context's stream.  The kernels' scratch (work counters, closest sphere/plane hit per pixel:
+ * 32 MiB + 2 KiB) is a fixed array inside the library, one copy per GPU, shared by every call on that GPU: calls
+ * that overlap on one GPU (two contexts or streams) race -- serialise them. */
+#define RTG_STATIC_MAX_PIXELS (1u << 21)
+int rtg_render_primary_static(rtg_scene *scene, const rtg_view *view, uint32_t width, uint32_t height,
+                              rtg_rect tile, rtg_hit *out_hits);
+
 /* Batched `Object::raycast(ray, None)` (src/render/object.rs:33-35,
  * src/render/scene_object.rs:19-36) for arbitrary rays: rays6 holds
  * orig.xyz, dir.xyz per ray.  out_points / out_counters may be NULL. */

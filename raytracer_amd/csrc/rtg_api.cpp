@@ -393,6 +393,13 @@ int rtg_ctx_create(int hip_device, rtg_ctx **out) {
         delete ctx;
         return fail(nullptr, RTG_E_HIP, "stream create on device %d: %s", hip_device, hipGetErrorString(e));
     }
+    e = static_scratch_init(hip_device);     // this GPU's address of the fixed scratch (rtg_render_primary_static)
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return fail(nullptr, RTG_E_HIP, "static scratch lookup on device %d: %s", hip_device, hipGetErrorString(e));
+    }
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return RTG_OK;

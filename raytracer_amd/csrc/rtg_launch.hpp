@@ -107,6 +107,10 @@ hipError_t launch_path_sort_gather(hipStream_t stream, const rtg_path *const *le
                                    uint64_t *keys_sorted, uint32_t *source, uint32_t *source_sorted, void *temp,
                                    size_t temp_bytes, rtg_path *out);
 
+// Looks up this GPU's copy of the fixed scratch array behind rtg_render_primary_static (rtg_static.hip); called
+// with `device` current, once per device (later calls return at once).
+hipError_t static_scratch_init(int device);
+
 hipError_t launch_selftest_div(hipStream_t stream, uint64_t seed, uint32_t blocks, uint32_t per_thread, uint32_t family,
                                uint64_t *out3);
 

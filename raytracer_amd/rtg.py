@@ -83,6 +83,7 @@ class Piece(C.Structure):
 
 
 COMM_ID_BYTES = 128
+STATIC_MAX_PIXELS = 1 << 21
 
 
 NODE_DTYPE = np.dtype([("lo", "<f8", 3), ("hi", "<f8", 3), ("child_begin", "<u4"), ("child_end", "<u4"),
@@ -136,6 +137,7 @@ _sig(lib.rtg_mesh_bounds, C.c_int, _vp, C.POINTER(C.c_double))
 _sig(lib.rtg_scene_create, C.c_int, _vp, C.POINTER(SceneDesc), C.POINTER(_vp))
 _sig(lib.rtg_scene_destroy, None, _vp)
 _sig(lib.rtg_render_primary, C.c_int, _vp, C.POINTER(View), C.c_uint32, C.c_uint32, Rect, _vp, _vp, _vp)
+_sig(lib.rtg_render_primary_static, C.c_int, _vp, C.POINTER(View), C.c_uint32, C.c_uint32, Rect, _vp)
 _sig(lib.rtg_trace, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp, _vp)
 _sig(lib.rtg_trace_paths, C.c_int, _vp, _vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64))
 _sig(lib.rtg_shade_direct, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, _vp, _vp)
@@ -669,6 +671,10 @@ class Scene:
         """Raw pointers (device addresses or numpy arrays); asynchronous for device pointers."""
         self.ctx._check(lib.rtg_render_primary(self._h, C.byref(view), width, height, Rect(*tile),
                                                _ptr(hits_ptr), _ptr(points_ptr), _ptr(counters_ptr)))
+
+    def render_primary_static(self, view, width, height, tile, hits_ptr):
+        """rtg_render_primary_static: device output only, no allocation inside the call."""
+        self.ctx._check(lib.rtg_render_primary_static(self._h, C.byref(view), width, height, Rect(*tile), _ptr(hits_ptr)))
 
     def trace(self, rays6, points=False, counters=False):
         rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
