@@ -220,10 +220,10 @@ def main():
         if args.traversal >= 0:
             c.set_option("traversal", args.traversal)
         if use_dist:
-            # The persistent kernel fills every block slot of the GPU for the whole frame, so a gather kernel on the
-            # second stream could only start when a frame drains.  Leaving 32 of the 1024 four-wave slots free lets
-            # RCCL's send/recv blocks run next to the traversal of the following frame.
-            c.set_option("max_blocks", 992)
+            # The persistent kernel fills every wave slot of the GPU for the whole frame (five waves per SIMD = 1280
+            # four-wave groups), so a gather kernel on the second stream could only start when a frame drains.
+            # Leaving 32 groups free lets RCCL's send/recv blocks run next to the traversal of the following frame.
+            c.set_option("max_blocks", 1248)
         for kv in args.opt:
             k, v = kv.split("=")
             c.set_option(k, int(v))

@@ -231,7 +231,8 @@ int rtg_ctx_synchronize(rtg_ctx *ctx);
  *               2 = persistent phase-scheduled waves over the threaded tree
  *   "tri_min" / "obj_min"               scheduling thresholds of traversal 2 (lanes)
  *   "patch_tri_min"                     lanes waiting for a patch leaf's Newton solve before one runs
- *   "max_blocks"                        persistent grid size of traversal 2
+ *   "max_blocks"                        persistent grid size of traversal 2 in four-wave groups (default: what the
+ *                                       GPU holds at once, 1280 for single-mesh scenes, 1024 otherwise)
  *   "pretest" 2 = on (default), 1 = off: single-precision box pre-test of traversal 2
  *   "stats" 2 = tally steps per phase in traversal 2 (diagnostics), 1 = off
  *   "frame_bands" 2 = rtg_render_frame issues an opaque scene's frame as two row bands on two streams, so one

@@ -448,6 +448,10 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) {
         ctx->traversal = (int)value;
         return RTG_OK;
     }
+    if (std::strcmp(key, "max_blocks") == 0 && value == 0) {     // 0: as many four-wave groups as the GPU holds
+        ctx->tune.max_blocks = 0;
+        return RTG_OK;
+    }
     if (value < 1 || value > (1 << 20)) return fail(ctx, RTG_E_INVALID, "option '%s': value out of range", key);
     if (std::strcmp(key, "tri_min") == 0) {
         ctx->tune.tri_min = (uint32_t)(value > 64 ? 64 : value);
@@ -1100,7 +1104,7 @@ int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *o
     if (n_rays == 0) return RTG_OK;
     if (!rays6) return fail(ctx, RTG_E_INVALID, "rtg_trace: rays6 is null");
     if (!out_hits && !out_points && !out_counters) return fail(ctx, RTG_E_INVALID, "rtg_trace: no output requested");
-    if (n_rays > (0x7FFFFFFFull * kBlock)) return fail(ctx, RTG_E_LIMIT, "rtg_trace: too many rays for one launch");
+    if (n_rays > 0xFFFFFFFFull) return fail(ctx, RTG_E_LIMIT, "rtg_trace: more than 2^32-1 rays in one call (split the batch)");
     if ((uintptr_t)rays6 % 16 != 0 && is_device_pointer(rays6))
         return fail(ctx, RTG_E_INVALID, "rtg_trace: device ray buffer must be 16-byte aligned");
     const void *d_rays = nullptr;
@@ -1263,6 +1267,8 @@ int shade_wavefront(rtg_ctx *ctx, const DevScene &ds, const rtg_light *d_lights,
     int rc;
     void *occ = nullptr;
     const uint64_t n_shadow = (uint64_t)n_lights * n_points;
+    if (n_shadow + n_rays > 0xFFFFFFFFull)
+        return fail(ctx, RTG_E_LIMIT, "more than 2^32-1 shadow and path rays in one launch (split the call)");
     if (n_shadow + n_rays != 0) {
         PhasedScratch ps;
         if ((rc = phased_scratch(ctx, ds, n_shadow + n_rays, ps)) != RTG_OK) return rc;
@@ -1384,7 +1390,7 @@ int rtg_shade_direct(rtg_scene *scene, const rtg_light *lights, uint32_t n_light
     if (!points) return fail(ctx, RTG_E_INVALID, "rtg_shade_direct: points is null");
     if (n_lights && !lights) return fail(ctx, RTG_E_INVALID, "rtg_shade_direct: lights is null");
     if (!rgb_out && !rgba8_out) return fail(ctx, RTG_E_INVALID, "rtg_shade_direct: no output requested");
-    if (n_points > (0x7FFFFFFFull * kBlock) || (n_lights != 0 && n_points > (1ull << 37) / n_lights))
+    if (n_points > 0xFFFFFFFFull || (n_lights != 0 && n_points > 0xFFFFFFFFull / n_lights))
         return fail(ctx, RTG_E_LIMIT, "rtg_shade_direct: too many points for one launch");
     const void *d_lights = nullptr, *d_points = nullptr;
     if ((rc = in_prepare(ctx, "in_lights", lights, (size_t)n_lights * sizeof(rtg_light), &d_lights)) != RTG_OK) return rc;
@@ -1434,7 +1440,7 @@ int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *li
     if ((rc = out_prepare(ctx, "out_hits", out_hits, n * sizeof(rtg_hit), oh)) != RTG_OK) return rc;
     DevScene ds;
     if ((rc = scene_for_launch(scene, tiles * kBlock, ds)) != RTG_OK) return rc;
-    if (ctx->traversal == 2 && scene->has_mesh && max_depth >= 1 && n_lights <= (1ull << 37) / n) {
+    if (ctx->traversal == 2 && scene->has_mesh && max_depth >= 1 && (uint64_t)n_lights * n <= 0x7FFFFFFFull) {
         // Every pixel is one primary hit plus its shadow rays unless that hit refracts, so the frame is passes of the
         // persistent kernel's building blocks (primary hit ids, point records, shadow rays, resolve); the pixels
         // whose primary hit has a dielectric material -- the only ones with a path tree -- are then redone by the

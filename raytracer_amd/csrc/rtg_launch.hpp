@@ -25,7 +25,7 @@ struct PhasedTuning {
     uint32_t tri_min = 20;
     uint32_t patch_tri_min = 24;   // lanes that must wait for a patch leaf's Newton solve before one runs
     uint32_t obj_min = 4;
-    uint32_t max_blocks = 1024;
+    uint32_t max_blocks = 0;     // persistent grid in four-wave groups; 0 = as many as the GPU holds at once
     uint32_t pretest = 1;        // single-precision box pre-test with exact fallback
     uint32_t stats = 0;          // diagnostics build: tally steps and lanes per phase
     // when set, the persistent kernel's launch records its execution window (the dispatch's own begin and end

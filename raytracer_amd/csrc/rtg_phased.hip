@@ -64,8 +64,13 @@ __device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgc
 // ---- ray sources ------------------------------------------------------------------
 // Every source also names the time below which a hit ends the query early (stop_time): -inf for closest-hit
 // queries; a shadow ray only has to know whether anything lies before the light.
+// kFiveWaves: the source's lean kernel variant is built for five waves per SIMD.  Coherent rays (camera, shadow)
+// gain from the extra latency hiding; an incoherent batch against a tree larger than the caches is bound by HBM
+// traffic, which more rays in flight only raise (measured: 64 M bench_mesh rays against 10 M triangles, 28.7 ms at
+// four waves, 31.1 ms at five).
 struct PrimarySource {
     static constexpr bool kEarlyStop = false;
+    static constexpr bool kFiveWaves = true;
     __device__ __forceinline__ double stop_time(uint64_t) const { return -kInf; }
     rtg_view view;
     uint32_t width, height;
@@ -97,6 +102,7 @@ struct PrimarySource {
 };
 struct BatchSource {
     static constexpr bool kEarlyStop = false;
+    static constexpr bool kFiveWaves = false;
     __device__ __forceinline__ double stop_time(uint64_t) const { return -kInf; }
     const double *rays6;
     uint64_t n;
@@ -116,6 +122,7 @@ struct BatchSource {
 // produce no ray and leave their output slot untouched.
 struct ShadowSource {
     static constexpr bool kEarlyStop = true;
+    static constexpr bool kFiveWaves = true;
     const rtg_point *points;
     const rtg_light *lights;
     uint64_t n_points;
@@ -154,6 +161,7 @@ struct ShadowSource {
 // the occluder table followed by the batch hits.
 struct ShadowAndBatchSource {
     static constexpr bool kEarlyStop = true;
+    static constexpr bool kFiveWaves = false;
     ShadowSource shadow;
     BatchSource batch;
     uint64_t n_shadow;
@@ -226,18 +234,30 @@ __device__ __forceinline__ bool box_hit_fast(V3 lo, V3 hi, const Ray &r, V3 rcp,
 // 2^-600 in magnitude the quotient cannot underflow, so `c_i < 0` is `n_i < 0`
 // (NaN and infinite n_i included).  Outside that window the wave falls back to
 // the divisions.  The barycentrics themselves are rebuilt for the winner only.
-__device__ __forceinline__ bool tri_hit_time_signs(V3 v0, V3 v1, V3 v2, const Ray &r, double &t_out) {
-    V3 e01 = v1 - v0, e12 = v2 - v1, e20 = v0 - v2;
-    V3 nt = cross(e01, e12);
+// The steps are kept in this order by scheduling barriers and the edge vectors are rebuilt where they are used (the
+// same subtractions, so the same bits): evaluated all at once the test holds some 75 registers, in sequence about 50,
+// which is what lets the kernel run five waves per SIMD.
+template <class LoadRay>
+__device__ __forceinline__ bool tri_hit_time_signs(V3 v0, V3 v1, V3 v2, LoadRay load_ray, double &t_out) {
+    V3 nt = cross(v1 - v0, v2 - v1);
+    __builtin_amdgcn_sched_barrier(0);
+    double nd, t;
+    V3 q;
+    {
+        const Ray r = load_ray();
+        nd = dot(nt, r.d);
+        t = dot(v0 - r.o, nt) / nd;          // d.dot(nt) has the same products in the same order as nt.dot(d)
+        q = ray_pos(r, t);
+    }
+    bool ok = !(nd > 0.0) && !(t < 0.0);
+    __builtin_amdgcn_sched_barrier(0);
     double denom = dot(nt, nt);
-    double nd = dot(nt, r.d);
-    bool ok = !(nd > 0.0);
-    double t = dot(v0 - r.o, nt) / nd;       // d.dot(nt) has the same products in the same order as nt.dot(d)
-    ok = ok && !(t < 0.0);
-    V3 q = ray_pos(r, t);
-    double n0 = dot(cross(e01, q - v0), nt);
-    double n1 = dot(cross(e12, q - v1), nt);
-    double n2 = dot(cross(e20, q - v2), nt);
+    double n0 = dot(cross(v1 - v0, q - v0), nt);
+    __builtin_amdgcn_sched_barrier(0);
+    double n1 = dot(cross(v2 - v1, q - v1), nt);
+    __builtin_amdgcn_sched_barrier(0);
+    double n2 = dot(cross(v0 - v2, q - v2), nt);
+    __builtin_amdgcn_sched_barrier(0);
     const double tiny = 0x1p-600;
     bool window = denom >= 0x1p-400 && denom <= 0x1p400 &&
                   (n0 == 0.0 || !(__builtin_fabs(n0) < tiny)) && (n1 == 0.0 || !(__builtin_fabs(n1) < tiny)) &&
@@ -376,13 +396,20 @@ struct WorkQueue {
 struct PreRay {
     float rx, ry, rz, nx, ny, nz, e2;
 };
-__device__ __forceinline__ PreRay make_pre_ray(const Ray &in, float coord_max) {
+// The costly part (three f64 divisions) is done when a chunk's rays are prepared with every lane busy; the rest is a
+// dozen f32 operations on the origin and runs where a lane picks its ray up, so only the reciprocals are parked.
+__device__ __forceinline__ void pre_ray_reciprocals(const Ray &in, float &rx, float &ry, float &rz) {
     const float qnan = __builtin_nanf("");
+    rx = in.d.x == 0.0 ? qnan : (float)(1.0 / in.d.x);
+    ry = in.d.y == 0.0 ? qnan : (float)(1.0 / in.d.y);
+    rz = in.d.z == 0.0 ? qnan : (float)(1.0 / in.d.z);
+}
+__device__ __forceinline__ PreRay pre_ray_from_reciprocals(const Ray &in, float rx, float ry, float rz, float coord_max) {
     float ox = (float)in.o.x, oy = (float)in.o.y, oz = (float)in.o.z;
     PreRay p;
-    p.rx = in.d.x == 0.0 ? qnan : (float)(1.0 / in.d.x);
-    p.ry = in.d.y == 0.0 ? qnan : (float)(1.0 / in.d.y);
-    p.rz = in.d.z == 0.0 ? qnan : (float)(1.0 / in.d.z);
+    p.rx = rx;
+    p.ry = ry;
+    p.rz = rz;
     p.nx = -(ox * p.rx);
     p.ny = -(oy * p.ry);
     p.nz = -(oz * p.rz);
@@ -391,6 +418,11 @@ __device__ __forceinline__ PreRay make_pre_ray(const Ray &in, float coord_max) {
     float ez = in.d.z == 0.0 ? 0.0f : (coord_max + __builtin_fabsf(oz)) * __builtin_fabsf(p.rz);
     p.e2 = __builtin_fmaxf(ex, __builtin_fmaxf(ey, ez)) * 0x1p-20f;
     return p;
+}
+__device__ __forceinline__ PreRay make_pre_ray(const Ray &in, float coord_max) {
+    float rx, ry, rz;
+    pre_ray_reciprocals(in, rx, ry, rz);
+    return pre_ray_from_reciprocals(in, rx, ry, rz, coord_max);
 }
 
 // SceneObject::raycast's `.min()` over the objects' hits (render/scene_object.rs:19-36, ordering
@@ -460,8 +492,18 @@ struct PhasedParams {
 constexpr int kPhasedBlock = RTG_PHASED_BLOCK;
 static_assert(kPhasedBlock % 64 == 0 && kPhasedBlock >= 64 && kPhasedBlock <= 256, "one to four waves per workgroup");
 
+// Waves per SIMD the kernel is compiled for.  The lean variants -- one mesh, triangles, no counters -- fit 96
+// registers and 8 KB of LDS per wave, so five waves share a SIMD (20 per CU: all of its 160 KB of LDS); the others
+// (several meshes, patches, counting, statistics) keep more state and stay at four.
+#ifndef RTG_PHASED_WAVES_LEAN
+#define RTG_PHASED_WAVES_LEAN 5
+#endif
+constexpr int phased_waves(bool five_ok, bool count, bool patch, bool keep, bool stats) {
+    return (!five_ok || count || patch || keep || stats) ? RTG_PHASED_WAVES : RTG_PHASED_WAVES_LEAN;
+}
+
 template <class Source, bool COUNT, bool PATCH, bool PRE, bool KEEP, bool STATS = false>
-__global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
+__global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUNT, PATCH, KEEP, STATS)) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
                                                           uint32_t *work_counters, PhasedParams prm,
                                                           rtg_hit *out_hits, rtg_ray_counters *out_counters,
                                                           const rtg_hit *__restrict__ prim_best) {
@@ -484,7 +526,9 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
     bool has_ray = false;
     // Per-ray state that is only touched between objects lives in LDS ([field][lane], 8-byte fields, so a
     // wave's access is conflict-free): the outer ray, the output slot and the scene-level best hit.
-    extern __shared__ double cold[];      // 3 * kPhasedBlock doubles, or 9 * kPhasedBlock when prm.keep_outer
+    // One mesh (no KEEP): best time and {leaf : 32 | output slot : 32} -- the object is the mesh whenever a leaf is
+    // held.  Several meshes: best time, {leaf : 32 | object : 32}, output slot, outer ray.
+    extern __shared__ double cold[];      // 2 * kPhasedBlock doubles, or 9 * kPhasedBlock in KEEP builds
     double *cold_lane = cold + threadIdx.x;
     enum { C_BEST_T = 0, C_BEST_ID, C_OUT, C_OX, C_OY, C_OZ, C_DX, C_DY, C_DZ };
 #define COLD(f) cold_lane[(f) * kPhasedBlock]
@@ -492,7 +536,7 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
     // mesh's space, pre-test ray) with every lane busy and parks them here ([field][slot of the wave]); a lane that
     // later needs a ray only copies one slot.
     __shared__ double stage_d[6 * kPhasedBlock];
-    __shared__ uint32_t stage_u[(Source::kEarlyStop ? 10 : 8) * kPhasedBlock];
+    __shared__ uint32_t stage_u[(Source::kEarlyStop ? 6 : 4) * kPhasedBlock];   // reciprocals, flags, (stop time)
 #define STG_D(slot, f) stage_d[(f) * kPhasedBlock + (threadIdx.x & ~63u) + (slot)]
 #define STG_U(slot, f) stage_u[(f) * kPhasedBlock + (threadIdx.x & ~63u) + (slot)]
     const bool need_outer = KEEP;
@@ -501,7 +545,30 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
     const GBytePtr first_slab = (GBytePtr)s.mesh_objects[0].mesh.slab + sizeof(MeshSlabHeader);
     const uint32_t first_end = s.mesh_objects[0].mesh.n_nodes;
     const bool first_fast_ok = s.mesh_objects[0].mesh.fast_div_ok != 0;
-    Ray in{};                     // ray in the current object's space
+    const float first_coord_max = s.mesh_objects[0].mesh.coord_max;
+    // The ray in the current object's space is only read by the triangle and patch steps and by the exact box test
+    // (rare with the pre-test on), so it is parked in LDS ([field][lane]) and read where it is used: twelve registers
+    // fewer are live across the node loop.
+    // KEEP builds (four waves, 128 registers, the outer ray already in LDS) keep it in registers instead.
+    __shared__ double in_lds[KEEP ? 1 : 6 * kPhasedBlock];
+    Ray in_reg{};
+#define IN_L(f) in_lds[(f) * kPhasedBlock + threadIdx.x]
+    auto load_in = [&]() {
+        if (KEEP) return in_reg;
+        return Ray{mk(IN_L(0), IN_L(1), IN_L(2)), mk(IN_L(3), IN_L(4), IN_L(5))};
+    };
+    auto store_in = [&](const Ray &r) {
+        if (KEEP) {
+            in_reg = r;
+            return;
+        }
+        IN_L(0) = r.o.x;
+        IN_L(1) = r.o.y;
+        IN_L(2) = r.o.z;
+        IN_L(3) = r.d.x;
+        IN_L(4) = r.d.y;
+        IN_L(5) = r.d.z;
+    };
     // Builds without the pre-test keep the reciprocal direction for the division-free f64 box test; builds with
     // it spend those registers on the f32 ray instead and use IEEE division wherever the pre-test cannot decide.
     V3 rcp = mk(0, 0, 0);
@@ -510,9 +577,13 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
     h.has = false;
     h.t = kInf;
     h.leaf = RTG_NONE;
-    uint32_t obj_i = 0, cur = 0, end = 0;
+    uint32_t obj_i = 0, cur = 0, end_v = 0;
     uint32_t leaf_cur = 0;        // next leaf to test; bit 31: the node (cur - 1) has several leaves, its range ends the TRI phase
-    GBytePtr slab = nullptr;      // the current mesh's hot-node array (slab + 64); everything else is an offset
+    // With one mesh in the scene (no KEEP) the tree is the same for every lane and every ray: its base and size stay
+    // wave-uniform (scalar registers); only scenes with several meshes carry them per lane.
+#define SLAB (KEEP ? slab_v : first_slab)
+#define END (KEEP ? end_v : first_end)
+    GBytePtr slab_v = nullptr;      // the current mesh's hot-node array (slab + 64); everything else is an offset
     bool pre = false;             // this ray/mesh pair may use the single-precision pre-test
     double t_stop = -kInf;        // sources with kEarlyStop: a held hit below this time ends the walk of a mesh
     // single-precision ray for the pre-test: reciprocal direction, -(origin * reciprocal), error bound, and the
@@ -527,11 +598,11 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
         bool more = false;
         if (leaf_cur & 0x80000000u) {    // rare: the owning node (cur - 1) lists several leaves
             typedef const vu4 __attribute__((address_space(1))) *U4;
-            vu4 tail = ((U4)((GNodePtr)(slab + (uint64_t)end * sizeof(HotNode)) + (cur - 1)))[3];
+            vu4 tail = ((U4)((GNodePtr)(SLAB + (uint64_t)END * sizeof(HotNode)) + (cur - 1)))[3];
             more = (leaf_cur & 0x7FFFFFFFu) + 1 < tail.z + tail.w;
         }
         leaf_cur++;
-        phase = more ? PH_TRI : (cur >= end ? PH_DONE : PH_NODE);
+        phase = more ? PH_TRI : (cur >= END ? PH_DONE : PH_NODE);
     };
 
     for (;;) {
@@ -558,8 +629,15 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
             // (1) a ray that has seen every object reports its closest hit
             if (phase == PH_OBJ && has_ray && obj_i >= s.n_mesh_objects) {
                 uint64_t best_id = (uint64_t)__double_as_longlong(COLD(C_BEST_ID));
-                uint64_t out_index = (uint64_t)__double_as_longlong(COLD(C_OUT));
-                uint32_t object = (uint32_t)best_id, leaf = (uint32_t)(best_id >> 32);
+                uint64_t out_index;
+                uint32_t object, leaf = (uint32_t)(best_id >> 32);
+                if (KEEP) {
+                    out_index = (uint64_t)__double_as_longlong(COLD(C_OUT));
+                    object = (uint32_t)best_id;
+                } else {
+                    out_index = (uint32_t)best_id;
+                    object = leaf != RTG_NONE ? first_id : RTG_NONE;
+                }
                 double t = COLD(C_BEST_T);
                 if (prim_best) {                  // the closest sphere / plane: lower (time, object index) wins
                     uint4 p = *reinterpret_cast<const uint4 *>(prim_best + out_index);
@@ -617,21 +695,18 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
                             STG_D(threadIdx.x & 63u, 5) = in0.d.z;
                             if (PRE) {
                                 if (o0.mesh.f32_ok != 0 && pre_ray_ok(in0)) flags |= 2u;
-                                PreRay pr = make_pre_ray(in0, o0.mesh.coord_max);
-                                STG_U(threadIdx.x & 63u, 0) = __float_as_uint(pr.rx);
-                                STG_U(threadIdx.x & 63u, 1) = __float_as_uint(pr.ry);
-                                STG_U(threadIdx.x & 63u, 2) = __float_as_uint(pr.rz);
-                                STG_U(threadIdx.x & 63u, 3) = __float_as_uint(pr.nx);
-                                STG_U(threadIdx.x & 63u, 4) = __float_as_uint(pr.ny);
-                                STG_U(threadIdx.x & 63u, 5) = __float_as_uint(pr.nz);
-                                STG_U(threadIdx.x & 63u, 6) = __float_as_uint(pr.e2);
+                                float rx, ry, rz;
+                                pre_ray_reciprocals(in0, rx, ry, rz);
+                                STG_U(threadIdx.x & 63u, 0) = __float_as_uint(rx);
+                                STG_U(threadIdx.x & 63u, 1) = __float_as_uint(ry);
+                                STG_U(threadIdx.x & 63u, 2) = __float_as_uint(rz);
                             }
                         }
-                        STG_U(threadIdx.x & 63u, 7) = flags;
+                        STG_U(threadIdx.x & 63u, 3) = flags;
                         if (Source::kEarlyStop && flags != 0) {
                             uint64_t tb = (uint64_t)__double_as_longlong(src.stop_time(chunk_base + (threadIdx.x & 63u)));
-                            STG_U(threadIdx.x & 63u, 8) = (uint32_t)tb;
-                            STG_U(threadIdx.x & 63u, 9) = (uint32_t)(tb >> 32);
+                            STG_U(threadIdx.x & 63u, 4) = (uint32_t)tb;
+                            STG_U(threadIdx.x & 63u, 5) = (uint32_t)(tb >> 32);
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
@@ -643,12 +718,12 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
                     uint32_t slot = (64u - chunk_left) + rank;
                     uint64_t item = chunk_base + slot;
                     {
-                        uint32_t flags = STG_U(slot, 7);
+                        uint32_t flags = STG_U(slot, 3);
                         if (flags & 1u) {
                             has_ray = true;
                             obj_i = 0;
                             if (Source::kEarlyStop) {
-                                t_stop = __longlong_as_double((long long)(((uint64_t)STG_U(slot, 9) << 32) | STG_U(slot, 8)));
+                                t_stop = __longlong_as_double((long long)(((uint64_t)STG_U(slot, 5) << 32) | STG_U(slot, 4)));
                             }
                             uint64_t out_index = src.slot_of(item);
                             if (need_outer) {
@@ -661,16 +736,23 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
                                 COLD(C_DY) = ray.d.y;
                                 COLD(C_DZ) = ray.d.z;
                             }
-                            COLD(C_OUT) = __longlong_as_double((long long)out_index);
                             COLD(C_BEST_T) = kInf;
-                            COLD(C_BEST_ID) = __longlong_as_double(-1ll);   // object = leaf = RTG_NONE
+                            if (KEEP) {
+                                COLD(C_OUT) = __longlong_as_double((long long)out_index);
+                                COLD(C_BEST_ID) = __longlong_as_double(-1ll);   // object = leaf = RTG_NONE
+                            } else {                                            // leaf = RTG_NONE, output slot
+                                COLD(C_BEST_ID) = __longlong_as_double((long long)(0xFFFFFFFF00000000ull | (uint32_t)out_index));
+                            }
                             ctr.nodes = 0;
                             ctr.tris = 0;
                             // straight into the first object's tree
-                            in = Ray{mk(STG_D(slot, 0), STG_D(slot, 1), STG_D(slot, 2)),
-                                     mk(STG_D(slot, 3), STG_D(slot, 4), STG_D(slot, 5))};
-                            slab = first_slab;
-                            end = first_end;
+                            const Ray in{mk(STG_D(slot, 0), STG_D(slot, 1), STG_D(slot, 2)),
+                                         mk(STG_D(slot, 3), STG_D(slot, 4), STG_D(slot, 5))};
+                            store_in(in);
+                            if (KEEP) {
+                                slab_v = first_slab;
+                                end_v = first_end;
+                            }
                             cur = 0;
                             h.has = false;
                             h.t = kInf;
@@ -681,13 +763,16 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
                             }
                             if (PRE) {
                                 pre = (flags & 2u) != 0;
-                                r32x = __uint_as_float(STG_U(slot, 0));
-                                r32y = __uint_as_float(STG_U(slot, 1));
-                                r32z = __uint_as_float(STG_U(slot, 2));
-                                np32x = __uint_as_float(STG_U(slot, 3));
-                                np32y = __uint_as_float(STG_U(slot, 4));
-                                np32z = __uint_as_float(STG_U(slot, 5));
-                                e2 = __uint_as_float(STG_U(slot, 6));
+                                PreRay pr = pre_ray_from_reciprocals(in, __uint_as_float(STG_U(slot, 0)),
+                                                                     __uint_as_float(STG_U(slot, 1)),
+                                                                     __uint_as_float(STG_U(slot, 2)), first_coord_max);
+                                r32x = pr.rx;
+                                r32y = pr.ry;
+                                r32z = pr.rz;
+                                np32x = pr.nx;
+                                np32y = pr.ny;
+                                np32z = pr.nz;
+                                e2 = pr.e2;
                                 b32 = __builtin_inff();          // == (float)h.t: an empty holder keeps t = +inf
                             }
                             phase = PH_NODE;
@@ -701,12 +786,10 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
             // (3) a ray that is done with one mesh enters the next one
             if (KEEP && phase == PH_OBJ && has_ray && obj_i < s.n_mesh_objects) {
                 const DevObject &o = s.mesh_objects[obj_i];
-                {
-                    Ray ray{mk(COLD(C_OX), COLD(C_OY), COLD(C_OZ)), mk(COLD(C_DX), COLD(C_DY), COLD(C_DZ))};
-                    in = inner_ray(o, ray);
-                }
-                slab = (GBytePtr)o.mesh.slab + sizeof(MeshSlabHeader);
-                end = o.mesh.n_nodes;
+                const Ray in = inner_ray(o, Ray{mk(COLD(C_OX), COLD(C_OY), COLD(C_OZ)), mk(COLD(C_DX), COLD(C_DY), COLD(C_DZ))});
+                store_in(in);
+                slab_v = (GBytePtr)o.mesh.slab + sizeof(MeshSlabHeader);
+                end_v = o.mesh.n_nodes;
                 cur = 0;
                 h.has = false;
                 h.t = kInf;
@@ -750,13 +833,13 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
             bool slow_any = PRE || wave_ballot(phase == PH_NODE && !fast) != 0;
             bool pre_all = PRE && wave_ballot(phase == PH_NODE && !pre) == 0;
             if (phase == PH_NODE) {
-                GNodePtr node = (GNodePtr)(slab + (uint64_t)end * sizeof(HotNode)) + cur;   // the full f64 node
+                GNodePtr node = (GNodePtr)(SLAB + (uint64_t)END * sizeof(HotNode)) + cur;   // the full f64 node
                 bool go;
                 uint32_t skip, leaf_ref;
                 if (pre_all) {
                     // single-precision pre-test on the 32-byte companion node
                     typedef const vu4 __attribute__((address_space(1))) *U4;
-                    U4 hp = (U4)(slab + (uint64_t)cur * sizeof(HotNode));
+                    U4 hp = (U4)(SLAB + (uint64_t)cur * sizeof(HotNode));
                     vu4 h0 = hp[0], h1 = hp[1];
                     vf2 cx = {__uint_as_float(h0.x), __uint_as_float(h0.y)};   // lo.x, hi.x
                     vf2 cy = {__uint_as_float(h0.z), __uint_as_float(h0.w)};
@@ -783,7 +866,7 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
                             V3 lo, hi;
                             uint4 tail;
                             load_node_g(node, lo, hi, tail);
-                            go = box_hit_div(lo, hi, in, h.t);
+                            go = box_hit_div(lo, hi, load_in(), h.t);
                         }
                     }
                 } else {
@@ -791,6 +874,7 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
                     uint4 tail;
                     load_node_g(node, lo, hi, tail);
                     if (COUNT) ctr.nodes++;
+                    const Ray in = load_in();
                     go = slow_any ? box_hit_div(lo, hi, in, h.t) : box_hit_fast(lo, hi, in, rcp, h.t);
                     skip = tail.x;
                     leaf_ref = tail.w == 0 ? 0xFFFFFFFFu : (tail.w == 1 ? tail.z : 0x80000000u);
@@ -804,11 +888,11 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
                 if (wave_ballot(to_leaf && (leaf_ref & 0x80000000u)) != 0) {    // rare: a node with several leaves
                     if (to_leaf && (leaf_ref & 0x80000000u)) {               // the range lives in the full node
                         typedef const vu4 __attribute__((address_space(1))) *U4;
-                        vu4 t = ((U4)((GNodePtr)(slab + (uint64_t)end * sizeof(HotNode)) + node_index))[3];
+                        vu4 t = ((U4)((GNodePtr)(SLAB + (uint64_t)END * sizeof(HotNode)) + node_index))[3];
                         leaf_cur = t.z | 0x80000000u;
                     }
                 }
-                if (phase == PH_NODE && cur >= end) phase = PH_DONE;   // traversal finished (resolved below)
+                if (phase == PH_NODE && cur >= END) phase = PH_DONE;   // traversal finished (resolved below)
             }
             m_tri = wave_ballot(phase == PH_TRI);
             if (STATS) tk_node += __builtin_amdgcn_s_memtime() - tk0;
@@ -827,17 +911,22 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
             if (phase == PH_TRI) {
                 V3 v0, v1, v2;
                 const uint32_t leaf = leaf_cur & 0x7FFFFFFFu;
-                load_tri_g((GTriPtr)(slab + (uint64_t)end * (sizeof(HotNode) + sizeof(DevNode))) + leaf, v0, v1, v2);
+                load_tri_g((GTriPtr)(SLAB + (uint64_t)END * (sizeof(HotNode) + sizeof(DevNode))) + leaf, v0, v1, v2);
                 double t;
                 bool some;
                 bool solve = false;
-                if (PATCH && ((const MeshSlabHeader *)(const uint8_t *)(slab - sizeof(MeshSlabHeader)))->patches) {
+                if (PATCH && ((const MeshSlabHeader *)(const uint8_t *)(SLAB - sizeof(MeshSlabHeader)))->patches) {
                     // patch leaf: only rays that hit the flat facet go on to the Newton solve, in a step of its own
                     V3 bary;
-                    solve = tri_hit_full(v0, v1, v2, in, t, bary);
+                    solve = tri_hit_full(v0, v1, v2, load_in(), t, bary);
                     some = false;
                 } else {
-                    some = tri_hit_time_signs(v0, v1, v2, in, t);
+#ifdef RTG_EXPERIMENT_NOTRI       // occupancy experiment only: no triangle ever hits, the test's registers vanish
+                    some = false;
+                    t = v0.x;
+#else
+                    some = tri_hit_time_signs(v0, v1, v2, load_in, t);
+#endif
                 }
                 if (COUNT) ctr.tris++;
                 if (solve) {
@@ -862,9 +951,10 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
                 if (phase == PH_SOLVE) {
                     V3 v0, v1, v2;
                     const uint32_t leaf = leaf_cur & 0x7FFFFFFFu;
-                    load_tri_g((GTriPtr)(slab + (uint64_t)end * (sizeof(HotNode) + sizeof(DevNode))) + leaf, v0, v1, v2);
-                    const MeshSlabHeader *hdr = (const MeshSlabHeader *)(const uint8_t *)(slab - sizeof(MeshSlabHeader));
+                    load_tri_g((GTriPtr)(SLAB + (uint64_t)END * (sizeof(HotNode) + sizeof(DevNode))) + leaf, v0, v1, v2);
+                    const MeshSlabHeader *hdr = (const MeshSlabHeader *)(const uint8_t *)(SLAB - sizeof(MeshSlabHeader));
                     PatchHit ph;
+                    const Ray in = load_in();
                     bool some = patch_leaf_hit<false>(hdr->patches, hdr->leaf_info + leaf, hdr->newton_steps, v0, v1, v2, in, ph);
                     holder_add(h, some, ph.tau, leaf);
                     if (PRE) b32 = (float)h.t;
@@ -888,12 +978,18 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
         // ---- a finished traversal reports to the scene-level minimum ------------------------
         if (phase == PH_DONE) {
             if (h.has) {
-                double best_t = COLD(C_BEST_T);
-                bool best_have = (uint32_t)__double_as_longlong(COLD(C_BEST_ID)) != RTG_NONE;
-                if (scene_better(best_have, best_t, h.t)) {
-                    uint32_t id = KEEP ? (uint32_t)s.mesh_objects[obj_i].index : first_id;
+                if (KEEP) {
+                    double best_t = COLD(C_BEST_T);
+                    bool best_have = (uint32_t)__double_as_longlong(COLD(C_BEST_ID)) != RTG_NONE;
+                    if (scene_better(best_have, best_t, h.t)) {
+                        uint32_t id = (uint32_t)s.mesh_objects[obj_i].index;
+                        COLD(C_BEST_T) = h.t;
+                        COLD(C_BEST_ID) = __longlong_as_double((long long)(((uint64_t)h.leaf << 32) | id));
+                    }
+                } else {                  // the only mesh: its holder is the scene's best
+                    uint64_t slot = (uint32_t)__double_as_longlong(COLD(C_BEST_ID));
                     COLD(C_BEST_T) = h.t;
-                    COLD(C_BEST_ID) = __longlong_as_double((long long)(((uint64_t)h.leaf << 32) | id));
+                    COLD(C_BEST_ID) = __longlong_as_double((long long)(((uint64_t)h.leaf << 32) | slot));
                 }
             }
             obj_i = obj_i + 1;
@@ -921,6 +1017,9 @@ __global__ __launch_bounds__(kPhasedBlock, RTG_PHASED_WAVES) void k_trace_phased
     }
 }
 
+#undef SLAB
+#undef END
+#undef IN_L
 #undef COLD
 #undef STG_D
 #undef STG_U
@@ -1011,7 +1110,10 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     // tune.max_blocks counts four-wave groups: the number of resident waves does not depend on the workgroup size
     const uint64_t per_group = 256 / kPhasedBlock;
     uint64_t want = (chunks + (kPhasedBlock / 64) - 1) / (kPhasedBlock / 64);
-    uint64_t most = (uint64_t)tune.max_blocks * per_group;
+    // tune.max_blocks == 0: fill the GPU -- 256 CUs x waves per SIMD four-wave groups for the variant that will run
+    const uint32_t fill = 256u * (uint32_t)phased_waves(Source::kFiveWaves, out_counters != nullptr, s.has_patches != 0,
+                                                        s.n_mesh_objects > 1, tune.stats != 0);
+    uint64_t most = (uint64_t)(tune.max_blocks ? tune.max_blocks : fill) * per_group;
     uint32_t grid = (uint32_t)(want < most ? want : most);
     if (grid == 0) grid = 1;
     // the outer ray is needed again when there are several meshes; only then does the dynamic LDS hold it (9 cold
@@ -1020,7 +1122,8 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     const bool keep = s.n_mesh_objects > 1;
     const bool pre = tune.pretest && s.any_f32_ok;
     PhasedParams prm{tune.tri_min, tune.obj_min, tune.patch_tri_min};
-    const size_t cold_bytes = (size_t)(keep ? 9 : 3) * kPhasedBlock * sizeof(double);
+    const size_t cold_bytes = (size_t)(keep ? 9 : 2) * kPhasedBlock * sizeof(double);
+    if (!keep && n_out > 0xFFFFFFFFull) return hipErrorInvalidValue;     // single-mesh builds keep a 32-bit output slot
     dim3 g(grid), b(kPhasedBlock);
 #define RTG_L(C, X, P, K, S)                                                                                      \
     hipExtLaunchKernelGGL((k_trace_phased<Source, C, X, P, K, S>), g, b, cold_bytes, stream, tune.time_start,    \

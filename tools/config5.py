@@ -45,7 +45,7 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     if world > 1:
-        ctx.set_option("max_blocks", 992)      # leave block slots for the RCCL kernels (see bench.py)
+        ctx.set_option("max_blocks", 1248)     # leave wave slots for the RCCL kernels (see bench.py)
     mesh = ctx.mesh(bvh)
     scene = ctx.scene([rtg.mesh_object(mesh, rtg.material((0.8, 0.7, 0.6)), rtg.transform(1.0 / bench.LOCAL_SCALE))])
 
