@@ -237,6 +237,9 @@ int rtg_ctx_synchronize(rtg_ctx *ctx);
  *   "stats" 2 = tally steps per phase in traversal 2 (diagnostics), 1 = off
  *   "frame_bands" 2 = rtg_render_frame issues an opaque scene's frame as two row bands on two streams, so one
  *                     band's launches run while the other's drain (default), 1 = one band
+ *   "sort_rays" 2 = rtg_trace (traversal 2) puts the batch into coherence order on the device first (key = direction
+ *                   octant | 30-bit Morton code of the origin; one radix sort), traces it and returns the answers in
+ *                   the caller's order; 1 = off (default: for one trace of a batch the sort costs more than it saves)
  *   "time_kernels" 2 = record each persistent-kernel launch's execution window (rtg_ctx_kernel_time), 1 = off */
 int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value);
 /* With option "time_kernels" = 2 every persistent-kernel launch behind rtg_render_primary / rtg_trace records its

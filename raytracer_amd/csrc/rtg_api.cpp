@@ -477,6 +477,10 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) {
         ctx->frame_bands = value >= 2 ? 2u : 1u;
         return RTG_OK;
     }
+    if (std::strcmp(key, "sort_rays") == 0) {
+        ctx->sort_rays = value > 1;              // 2 = on, 1 = off
+        return RTG_OK;
+    }
     if (std::strcmp(key, "time_kernels") == 0) {
         ctx->time_kernels = value > 1;           // 2 = on, 1 = off
         return RTG_OK;
@@ -1123,8 +1127,34 @@ int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *o
         if (op.dev && !hits && (rc = scratch_get(ctx, "points_hits", n_rays * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
         PhasedTuning tune;
         if ((rc = tuning_for_launch(ctx, ds.n_mesh_objects != 0, tune)) != RTG_OK) return rc;
-        HIP_TRY(ctx, launch_trace_phased(ctx->stream, ds, (const double *)d_rays, n_rays, ps, tune,
-                                         (rtg_hit *)hits, (rtg_ray_counters *)oc.dev));
+        if (ctx->sort_rays && ds.n_mesh_objects != 0 && n_rays >= 4096) {
+            // trace the batch in coherence order, hand the answers back in the caller's order
+            RaySortScratch w;
+            void *v = nullptr, *sorted = nullptr, *tmp_hits = nullptr, *tmp_ctr = nullptr;
+            if ((rc = scratch_get(ctx, "sort_box", 6 * sizeof(unsigned long long), &v)) != RTG_OK) return rc;
+            w.box = (unsigned long long *)v;
+            if ((rc = scratch_get(ctx, "sort_keys", n_rays * sizeof(uint64_t), &v)) != RTG_OK) return rc;
+            w.keys = (uint64_t *)v;
+            if ((rc = scratch_get(ctx, "sort_keys_sorted", n_rays * sizeof(uint64_t), &v)) != RTG_OK) return rc;
+            w.keys_sorted = (uint64_t *)v;
+            if ((rc = scratch_get(ctx, "sort_index", n_rays * sizeof(uint32_t), &v)) != RTG_OK) return rc;
+            w.index = (uint32_t *)v;
+            if ((rc = scratch_get(ctx, "sort_perm", n_rays * sizeof(uint32_t), &v)) != RTG_OK) return rc;
+            w.perm = (uint32_t *)v;
+            w.temp_bytes = ray_sort_temp_bytes(n_rays);
+            if ((rc = scratch_get(ctx, "sort_temp", w.temp_bytes, &w.temp)) != RTG_OK) return rc;
+            if ((rc = scratch_get(ctx, "sort_rays", n_rays * 6 * sizeof(double), &sorted)) != RTG_OK) return rc;
+            if ((rc = scratch_get(ctx, "sort_hits", n_rays * sizeof(rtg_hit), &tmp_hits)) != RTG_OK) return rc;
+            if (oc.dev && (rc = scratch_get(ctx, "sort_counters", n_rays * sizeof(rtg_ray_counters), &tmp_ctr)) != RTG_OK) return rc;
+            HIP_TRY(ctx, launch_ray_sort(ctx->stream, (const double *)d_rays, n_rays, w, (double *)sorted));
+            HIP_TRY(ctx, launch_trace_phased(ctx->stream, ds, (const double *)sorted, n_rays, ps, tune, (rtg_hit *)tmp_hits,
+                                             (rtg_ray_counters *)tmp_ctr));
+            HIP_TRY(ctx, launch_ray_unsort(ctx->stream, (const rtg_hit *)tmp_hits, (const rtg_ray_counters *)tmp_ctr, w.perm,
+                                           n_rays, (rtg_hit *)hits, (rtg_ray_counters *)oc.dev));
+        } else {
+            HIP_TRY(ctx, launch_trace_phased(ctx->stream, ds, (const double *)d_rays, n_rays, ps, tune,
+                                             (rtg_hit *)hits, (rtg_ray_counters *)oc.dev));
+        }
         if (op.dev)
             HIP_TRY(ctx, launch_points_batch(ctx->stream, ds, (const double *)d_rays, n_rays, (const rtg_hit *)hits,
                                              (rtg_point *)op.dev));

@@ -26,6 +26,7 @@ struct rtg_ctx {
     // option "time_kernels": execution windows of the persistent kernel launches behind rtg_render_primary and
     // rtg_trace, summed by rtg_ctx_kernel_time
     bool time_kernels = false;
+    bool sort_rays = false;      // option "sort_rays": rtg_trace orders the batch for coherence before tracing it
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, idle_events;
     // rtg_render_frame renders a frame of an opaque scene as two row bands on two streams (option "frame_bands"):
     // `side` is an internal context (own stream and scratch) for the second band, joined back by events

@@ -107,6 +107,22 @@ hipError_t launch_path_sort_gather(hipStream_t stream, const rtg_path *const *le
                                    uint64_t *keys_sorted, uint32_t *source, uint32_t *source_sorted, void *temp,
                                    size_t temp_bytes, rtg_path *out);
 
+// Ray batches put into coherence order on the device (rtg_sort.hip): key = direction octant | 30-bit Morton code of
+// the origin inside the batch's bounding box, one radix sort of (key, index) pairs, rays gathered into key order;
+// afterwards the results are scattered back with the same permutation.
+struct RaySortScratch {
+    unsigned long long *box = nullptr;     // 6 words
+    uint64_t *keys = nullptr, *keys_sorted = nullptr;
+    uint32_t *index = nullptr, *perm = nullptr;
+    void *temp = nullptr;
+    size_t temp_bytes = 0;
+};
+size_t ray_sort_temp_bytes(uint64_t n);
+hipError_t launch_ray_sort(hipStream_t stream, const double *rays6, uint64_t n, const RaySortScratch &scratch,
+                           double *sorted_rays6);
+hipError_t launch_ray_unsort(hipStream_t stream, const rtg_hit *hits, const rtg_ray_counters *counters, const uint32_t *perm,
+                             uint64_t n, rtg_hit *out_hits, rtg_ray_counters *out_counters);
+
 // Looks up this GPU's copy of the fixed scratch array behind rtg_render_primary_static (rtg_static.hip); called
 // with `device` current, once per device (later calls return at once).
 hipError_t static_scratch_init(int device);

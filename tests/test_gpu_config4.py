@@ -62,7 +62,14 @@ def test_config4_64m_incoherent_rays_10m_triangles(gpu_ctx):
     gpu_ctx.synchronize()
     back = torch.roll(hits1.view(N_RAYS, 16), shifts=-shift, dims=0).contiguous().view(-1)
     assert _device_hits_differ(torch, hits2, back, N_RAYS) == 0
-    del rolled, back, hits1
+    del rolled, back
+    # sorted on the device (octant | Morton key, radix sort, gather, trace, scatter back): the same answers
+    gpu_ctx.set_option("sort_rays", 2)
+    scene.trace_raw(d_rays.data_ptr(), N_RAYS, hits1.data_ptr())
+    gpu_ctx.synchronize()
+    gpu_ctx.set_option("sort_rays", 1)
+    assert _device_hits_differ(torch, hits2, hits1, N_RAYS) == 0
+    del hits1
 
     # oracle sample: 262 144 rays of the batch through the tree the device built
     m = 1 << 18

@@ -96,6 +96,13 @@ def test_incoherent_batch_rays(gpu_ctx, traversal):
     perm, sorted_rays = rtg.sort_rays(bvh.bounds(), rays)
     s_hits, _, _ = pair.gpu.trace(sorted_rays)
     assert scenes.same_hits(s_hits, g_hits[perm])
+    # the device-side sort (key, radix sort, gather, trace, scatter back) returns the caller's order unchanged
+    gpu_ctx.set_option("sort_rays", 2)
+    d_hits, d_pts, d_ctr = pair.gpu.trace(rays, points=True, counters=True)
+    gpu_ctx.set_option("sort_rays", 1)
+    _assert_hits_equal(d_hits, c_hits)
+    _assert_points_equal(d_pts, c_pts)
+    assert np.array_equal(d_ctr, c_ctr)
     gpu_ctx.set_option("traversal", 2)
 
 
@@ -409,10 +416,18 @@ def test_many_instances_with_general_affine_transforms(gpu_ctx, traversal):
     assert not scenes.float_bits_differ(g_rgb, c_rgb).any()
     assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1
     rays = np.concatenate([rng.uniform(-1, 1, size=(20000, 3)) + [0, 0, -1], rng.normal(size=(20000, 3))], axis=1)
+    rays[::1000, 0] = np.nan                                           # origins the sort key cannot place
+    rays[500::1000, 1] = np.inf
     g_hits, g_pts, _ = pair.gpu.trace(rays, points=True)
     c_hits, c_pts, _ = pair.cpu.trace(rays, points=True)
     _assert_hits_equal(g_hits, c_hits)
     _assert_points_equal(g_pts, c_pts)
+    if traversal == 2:                                                 # the same through the device-side ray sort
+        gpu_ctx.set_option("sort_rays", 2)
+        s_hits, s_pts, _ = pair.gpu.trace(rays, points=True)
+        gpu_ctx.set_option("sort_rays", 1)
+        _assert_hits_equal(s_hits, c_hits)
+        _assert_points_equal(s_pts, c_pts)
     gpu_ctx.set_option("traversal", 2)
 
 
