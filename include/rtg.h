@@ -360,6 +360,59 @@ int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *li
                      uint32_t n_lights, uint32_t width, uint32_t height, rtg_rect tile,
                      uint32_t max_depth, double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits);
 
+/* ---- photon map (indirect light through specular surfaces) -------------- */
+
+/* One stored photon: `Photon` and the position of its `KdEntry` (src/render/renderer.rs:63-71,129-136): a path
+ * from a light that met at least one specular surface before it landed. */
+typedef struct {
+    double position[3];         /* path.raycast_point.position: the kd-tree key */
+    double origin[3];           /* Photon::origin: the light's centre */
+    double dir[2];              /* Photon::dir, `ZenithY` (zenith, y) of the emission direction (src/geo/sphere.rs:19-33) */
+    double light[3];            /* light.color * path.attenuation */
+    uint32_t surface_object[3]; /* Photon::manifold: the surfaces the path bounced off, in order -- object index ... */
+    uint32_t surface_leaf[3];   /* ... and mesh leaf index (RTG_NONE for spheres and planes) */
+    uint32_t n_bounces;         /* Photon::modes.len() == manifold.len(): 1 .. max_depth - 1 (at most 3) */
+    uint32_t modes;             /* bit i set: bounce i was SpecularMode::Refract */
+    uint32_t light_index;
+    uint32_t _pad;
+} rtg_photon;
+
+typedef struct rtg_photon_map rtg_photon_map;
+
+/* The photon pass of `Renderer::render` (src/render/renderer.rs:116-138): for every light l and every direction
+ * dirs2[(l * count_per_light + i) * 2 ..] (a `ZenithY`; the reference draws them with `Sphere::fibonacci_sphere`
+ * from an entropy-seeded generator, so the caller supplies them) the ray from the light's centre is followed
+ * through `raytrace_all_specular` and every hit behind at least one specular bounce becomes a photon.  Directions
+ * are turned into rays on the host (`ZenithY::into_normal` uses the platform's sin/cos, as the reference does); the
+ * paths are traced on the GPU.  max_depth is the reference's constant 4 (at most 4).  When more than `capacity`
+ * photons result nothing is written and RTG_E_LIMIT is returned; *n_photons is set either way. */
+int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const double *dirs2,
+                     uint64_t count_per_light, uint32_t max_depth, rtg_photon *out_photons, uint64_t capacity,
+                     uint64_t *n_photons);
+
+/* `KdTree::new(photons)` (src/tree/kd_tree.rs:74-95): a balanced k-d tree over the photons' positions, kept on the
+ * GPU together with the photon records.  `photons` is host memory and is copied. */
+int rtg_photon_map_create(rtg_ctx *ctx, const rtg_photon *photons, uint64_t n_photons, rtg_photon_map **out);
+void rtg_photon_map_destroy(rtg_photon_map *map);
+
+/* `KdTree::nearest(&p, k)` (src/tree/kd_tree.rs:115-154) for a batch of query points: out_index[q * k + j] is the
+ * index (in the array given to rtg_photon_map_create) of the j-th nearest photon of query q, out_distance its
+ * distance, ascending; slots beyond the number of photons hold RTG_NONE / +inf.  k <= 16.  Which of several
+ * photons at exactly the same distance is reported is not defined (in the reference it depends on the heap). */
+int rtg_photon_map_nearest(rtg_photon_map *map, const double *queries3, uint64_t n_queries, uint32_t k,
+                           uint32_t *out_index, double *out_distance);
+
+/* `compute_indirect_irrad` (src/render/renderer.rs:206-265) for n surface points: for each of the photon_samples
+ * nearest photons the emission direction is corrected by newton_steps Newton steps so that the photon's path --
+ * followed through the same surfaces with the same reflect / refract choices, in forward-mode dual numbers
+ * (`Der<2>`, src/math/scalar.rs:72-128) -- lands on the point's own surface coordinates; the corrected photon is
+ * traced through the whole scene, kept if it lands within newton_epsilon of the point, and contributes
+ * light / (4 pi |dP/da x dP/db|).  One photon per light (the last of the nearest ones), summed in light order.
+ * rgb_out: 3 doubles per point (zeros for points with manifold_len 0).  Scenes with patch sets are not supported.
+ * sin / cos of the direction are the GPU's, so results agree with a CPU evaluation to rounding, not bit for bit. */
+int rtg_indirect_irrad(rtg_scene *scene, rtg_photon_map *map, const rtg_point *points, uint64_t n_points,
+                       uint32_t photon_samples, uint32_t newton_steps, double newton_epsilon, double *rgb_out);
+
 /* ---- several GPUs ----------------------------------------------------- */
 
 /* The path has no exchange during compute: the scene is replicated and pixels / frames are independent

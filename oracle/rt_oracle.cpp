@@ -1084,6 +1084,8 @@ Material material_of_slot(const orc_scene &s, uint32_t slot) {
 }
 } // namespace
 
+#include "rt_oracle_photon.hpp"
+
 // =============================== C API ========================================
 extern "C" {
 
@@ -1479,6 +1481,230 @@ int orc_render_frame(const orc_scene *s, const rtg_view *view, const rtg_light *
         }
     });
     return 0;
+}
+
+} // extern "C"
+
+// ---- photon map -----------------------------------------------------------------------
+struct orc_kd {
+    std::vector<gen::KdEntry> tree;
+};
+
+extern "C" {
+
+// op: 0 add, 1 sub, 2 mul, 3 div, 4 neg, 5 sqrt, 6 sin, 7 cos, 8 abs, 9 minimum, 10 maximum (a, b, out = v, d0, d1)
+void orc_der2_op(int op, const double a[3], const double b[3], double out[3]) {
+    gen::Der2 x{a[0], {a[1], a[2]}}, y{b[0], {b[1], b[2]}}, r{QNAN, {QNAN, QNAN}};
+    switch (op) {
+    case 0: r = x + y; break;
+    case 1: r = x - y; break;
+    case 2: r = x * y; break;
+    case 3: r = x / y; break;
+    case 4: r = -x; break;
+    case 5: r = gen::s_sqrt(x); break;
+    case 6: r = gen::s_sin(x); break;
+    case 7: r = gen::s_cos(x); break;
+    case 8: r = gen::s_abs(x); break;
+    case 9: r = gen::s_minimum(x, y); break;
+    case 10: r = gen::s_maximum(x, y); break;
+    default: break;
+    }
+    out[0] = r.v;
+    out[1] = r.d[0];
+    out[2] = r.d[1];
+}
+// derived PartialOrd of Der<2>: -1, 0, 1, or 2 when the values have no order
+int orc_der2_partial_cmp(const double a[3], const double b[3]) {
+    return gen::der_partial_cmp(gen::Der2{a[0], {a[1], a[2]}}, gen::Der2{b[0], {b[1], b[2]}});
+}
+// the reference's own Der test (math/scalar.rs:360-367): var(1,0) + var(2,1) + from(3)
+void orc_der2_known_answer(double out[3]) {
+    gen::Der2 f = gen::der_var(1.0, 0) + gen::der_var(2.0, 1) + gen::der_from(3.0);
+    out[0] = f.v;
+    out[1] = f.d[0];
+    out[2] = f.d[1];
+}
+void orc_zenith_y_into_normal(const double dir2[2], double out[3]) {
+    gen::Vec3T<double> n = gen::zenith_y_into_normal<double>(dir2[0], dir2[1]);
+    for (int i = 0; i < 3; i++) out[i] = n[i];
+}
+// Sphere::fibonacci_sphere (geo/sphere.rs:52-80) with the two uniform draws per direction supplied by the caller
+void orc_fibonacci_sphere(uint64_t count, const double *uniform2, double *out_dirs2) {
+    const double c = (double)count;
+    const double phi = PI * (3.0 - std::sqrt(5.0));
+    const double d = 2.0 * PI / phi;
+    const double dydi = 2.0 / (c + d);
+    const double dydj = dydi * d;
+    for (uint64_t i = 0; i < count; i++) {
+        double x = (double)i + uniform2[i * 2], y = uniform2[i * 2 + 1];
+        out_dirs2[i * 2] = std::fmod(phi * x, 2.0 * PI);
+        out_dirs2[i * 2 + 1] = -1.0 + dydi * x + dydj * y;
+    }
+}
+
+orc_kd *orc_kd_create(const double *positions3, uint64_t n) {
+    orc_kd *kd = new orc_kd();
+    kd->tree.resize(n);
+    for (uint64_t i = 0; i < n; i++) {
+        kd->tree[i].position = mk(positions3[i * 3], positions3[i * 3 + 1], positions3[i * 3 + 2]);
+        kd->tree[i].value = (uint32_t)i;
+    }
+    gen::kd_build_rec(kd->tree.data(), kd->tree.size());
+    return kd;
+}
+void orc_kd_destroy(orc_kd *kd) { delete kd; }
+// KdTree::assert_kd_tree over every subtree (tree/kd_tree.rs:98-114 checks the root's split): 1 when it holds
+static bool kd_check_rec(const gen::KdEntry *t, size_t len) {
+    if (len == 0) return true;
+    size_t c = len / 2;
+    int axis = t[c].axis;
+    for (size_t i = 0; i < c; i++)
+        if (!(t[i].position[axis] <= t[c].position[axis])) return false;
+    for (size_t i = c + 1; i < len; i++)
+        if (!(t[c].position[axis] <= t[i].position[axis])) return false;
+    return kd_check_rec(t, c) && kd_check_rec(t + c + 1, len - c - 1);
+}
+int orc_kd_check(const orc_kd *kd) { return kd_check_rec(kd->tree.data(), kd->tree.size()) ? 1 : 0; }
+// KdTree::nearest per query; slots beyond the number of entries: RTG_NONE / +inf
+void orc_kd_nearest(const orc_kd *kd, const double *queries3, uint64_t n_queries, uint32_t k, uint32_t *out_index,
+                    double *out_distance, int threads) {
+    parallel_for(n_queries, threads, [&](uint64_t q) {
+        std::vector<gen::KdNeighbor> nb = gen::kd_nearest(kd->tree, mk(queries3[q * 3], queries3[q * 3 + 1], queries3[q * 3 + 2]), k);
+        for (uint32_t j = 0; j < k; j++) {
+            out_index[q * k + j] = j < nb.size() ? nb[j].value : RTG_NONE;
+            out_distance[q * k + j] = j < nb.size() ? nb[j].distance : INF;
+        }
+    });
+}
+// what the reference's test compares `nearest` with (tree/kd_tree.rs:262-264): every distance, sorted (by
+// distance under real_cmp, then by value)
+void orc_kd_nearest_brute(const double *positions3, uint64_t n, const double *queries3, uint64_t n_queries, uint32_t k,
+                          uint32_t *out_index, double *out_distance, int threads) {
+    parallel_for(n_queries, threads, [&](uint64_t q) {
+        V3 query = mk(queries3[q * 3], queries3[q * 3 + 1], queries3[q * 3 + 2]);
+        std::vector<gen::KdNeighbor> all(n);
+        for (uint64_t i = 0; i < n; i++)
+            all[i] = gen::KdNeighbor{length(query - mk(positions3[i * 3], positions3[i * 3 + 1], positions3[i * 3 + 2])), (uint32_t)i};
+        size_t keep = std::min<size_t>(k, n);
+        std::partial_sort(all.begin(), all.begin() + keep, all.end(), [](const gen::KdNeighbor &a, const gen::KdNeighbor &b) {
+            int c = real_cmp(a.distance, b.distance);
+            return c != 0 ? c < 0 : a.value < b.value;
+        });
+        for (uint32_t j = 0; j < k; j++) {
+            out_index[q * k + j] = j < keep ? all[j].value : RTG_NONE;
+            out_distance[q * k + j] = j < keep ? all[j].distance : INF;
+        }
+    });
+}
+
+// the photon pass of Renderer::render (render/renderer.rs:116-138) with the directions supplied
+int orc_photons_emit(const orc_scene *s, const rtg_light *lights, uint32_t n_lights, const double *dirs2,
+                     uint64_t count_per_light, uint32_t max_depth, rtg_photon *out, uint64_t capacity, uint64_t *n_photons) {
+    uint64_t total = 0;
+    for (uint32_t l = 0; l < n_lights; l++) {
+        const V3 origin = mk(lights[l].position[0], lights[l].position[1], lights[l].position[2]);
+        const V3 color = mk(lights[l].color[0], lights[l].color[1], lights[l].color[2]);
+        for (uint64_t i = 0; i < count_per_light; i++) {
+            const double *dir = dirs2 + (l * count_per_light + i) * 2;
+            gen::Vec3T<double> n = gen::zenith_y_into_normal<double>(dir[0], dir[1]);
+            std::vector<PathPoint> paths;
+            Counters c;
+            all_specular_rec(*s, Ray{origin, mk(n[0], n[1], n[2])}, 1.0, 0, max_depth, paths, c);
+            for (const PathPoint &pp : paths) {
+                if (pp.depth == 0) continue;
+                if (total < capacity) {
+                    rtg_photon &o = out[total];
+                    std::memset(&o, 0, sizeof(o));
+                    V3 light = color * pp.attenuation;
+                    for (int k = 0; k < 3; k++) {
+                        o.position[k] = pp.point.position[k];
+                        o.origin[k] = origin[k];
+                        o.light[k] = light[k];
+                        o.surface_object[k] = RTG_NONE;
+                        o.surface_leaf[k] = RTG_NONE;
+                    }
+                    o.dir[0] = dir[0];
+                    o.dir[1] = dir[1];
+                    o.n_bounces = pp.depth;
+                    o.modes = pp.modes;
+                    o.light_index = l;
+                    uint32_t at = pp.parent;                     // ancestors, deepest first
+                    for (uint32_t d = pp.depth; d-- > 0;) {
+                        const PathPoint &a = paths[at];
+                        if (d < 3) {
+                            const Manifold &m = a.point.manifold;
+                            o.surface_object[d] = m.array[m.len - 1];
+                            o.surface_leaf[d] = m.len == 2 ? m.array[0] : RTG_NONE;
+                        }
+                        at = a.parent;
+                    }
+                }
+                total++;
+            }
+        }
+    }
+    *n_photons = total;
+    return total <= capacity ? 0 : -1;
+}
+
+// compute_indirect_irrad (render/renderer.rs:206-265) per point; photons indexed as given to orc_kd_create
+int orc_indirect_irrad(const orc_scene *s, const orc_kd *kd, const rtg_photon *photons, const rtg_point *points,
+                       uint64_t n_points, uint32_t photon_samples, uint32_t newton_steps, double newton_epsilon,
+                       uint32_t max_depth, double *rgb_out, int threads) {
+    parallel_for(n_points, threads, [&](uint64_t i) {
+        V3 c = gen::compute_indirect_irrad(*s, kd->tree, photons, points[i], photon_samples, newton_steps, newton_epsilon, max_depth);
+        for (int k = 0; k < 3; k++) rgb_out[i * 3 + k] = c[k];
+    });
+    return 0;
+}
+// One photon's corrected landing point, for inspection: the Newton iteration and the final full trace of
+// compute_indirect_irrad for photon `ph` against point `p`.  out: dir[2] after the steps, landed (0/1), position v[3],
+// d/da[3], d/db[3], residual separation after each step (2 * newton_steps, NaN when the step did not run).
+void orc_photon_adjust(const orc_scene *s, const rtg_photon *ph, const rtg_point *p, uint32_t newton_steps, uint32_t max_depth,
+                       double *out12, double *out_seps) {
+    using namespace gen;
+    double dir[2] = {ph->dir[0], ph->dir[1]};
+    std::vector<OptManifold> fm;
+    std::vector<int> modes;
+    for (uint32_t i = 0; i < ph->n_bounces; i++) {
+        fm.push_back(OptManifold{true, manifold_of(ph->surface_object[i], ph->surface_leaf[i])});
+        modes.push_back((ph->modes >> i) & 1u);
+    }
+    fm.push_back(OptManifold{true, Manifold{{p->manifold[0], p->manifold[1]}, p->manifold_len}});
+    const Vec3T<Der2> origin = vcast<Der2>(mk(ph->origin[0], ph->origin[1], ph->origin[2]));
+    for (uint32_t k = 0; k < 2 * newton_steps; k++) out_seps[k] = QNAN;
+    for (uint32_t step = 0; step < newton_steps; step++) {
+        RayT<Der2> ray{origin, zenith_y_into_normal(der_var(dir[0], 0), der_var(dir[1], 1))};
+        std::vector<PathT<Der2>> hit;
+        std::vector<Manifold> om;
+        std::vector<int> omodes;
+        all_specular_filtered(*s, ray, der_from(1.0), fm.data(), fm.size(), modes.data(), modes.size(), true, max_depth, om, omodes, hit);
+        if (hit.empty()) break;
+        Der2 sep[2] = {hit[0].point.mp[0] - der_from(p->manifold_point[0]), hit[0].point.mp[1] - der_from(p->manifold_point[1])};
+        out_seps[step * 2] = sep[0].v;
+        out_seps[step * 2 + 1] = sep[1].v;
+        Mat<2> jac = {{{sep[0].d[0], sep[0].d[1]}, {sep[1].d[0], sep[1].d[1]}}};
+        Mat<2> inv = inverse2(jac);
+        const double sv[2] = {sep[0].v, sep[1].v};
+        double st[2];
+        matvec(inv, sv, st);
+        dir[0] = dir[0] - st[0];
+        dir[1] = dir[1] - st[1];
+    }
+    RayT<Der2> ray{origin, zenith_y_into_normal(der_var(dir[0], 0), der_var(dir[1], 1))};
+    std::vector<PathT<Der2>> real_photon;
+    std::vector<Manifold> om;
+    std::vector<int> omodes;
+    all_specular_filtered(*s, ray, der_from(1.0), (const OptManifold *)nullptr, 0, modes.data(), modes.size(), true, max_depth, om,
+                          omodes, real_photon);
+    out12[0] = dir[0];
+    out12[1] = dir[1];
+    out12[2] = real_photon.empty() ? 0.0 : 1.0;
+    for (int k = 0; k < 3; k++) {
+        out12[3 + k] = real_photon.empty() ? QNAN : real_photon[0].point.position[k].v;
+        out12[6 + k] = real_photon.empty() ? QNAN : real_photon[0].point.position[k].d[0];
+        out12[9 + k] = real_photon.empty() ? QNAN : real_photon[0].point.position[k].d[1];
+    }
 }
 
 } // extern "C"

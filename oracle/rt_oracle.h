@@ -122,6 +122,29 @@ int orc_render_frame(const orc_scene *s, const rtg_view *view, const rtg_light *
                      uint32_t max_depth, double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits,
                      int threads);
 
+/* ---- photon map: k-d tree, Der<2>, caustic correction (PARITY UNPINNED beyond the k-d tree and Der tests) ---- */
+typedef struct orc_kd orc_kd;
+/* op: 0 add, 1 sub, 2 mul, 3 div, 4 neg, 5 sqrt, 6 sin, 7 cos, 8 abs, 9 minimum, 10 maximum; Der<2> as (v, d0, d1) */
+void orc_der2_op(int op, const double a[3], const double b[3], double out[3]);
+int orc_der2_partial_cmp(const double a[3], const double b[3]);
+void orc_der2_known_answer(double out[3]);
+void orc_zenith_y_into_normal(const double dir2[2], double out[3]);
+void orc_fibonacci_sphere(uint64_t count, const double *uniform2, double *out_dirs2);
+orc_kd *orc_kd_create(const double *positions3, uint64_t n);
+void orc_kd_destroy(orc_kd *kd);
+int orc_kd_check(const orc_kd *kd);
+void orc_kd_nearest(const orc_kd *kd, const double *queries3, uint64_t n_queries, uint32_t k, uint32_t *out_index,
+                    double *out_distance, int threads);
+void orc_kd_nearest_brute(const double *positions3, uint64_t n, const double *queries3, uint64_t n_queries, uint32_t k,
+                          uint32_t *out_index, double *out_distance, int threads);
+int orc_photons_emit(const orc_scene *s, const rtg_light *lights, uint32_t n_lights, const double *dirs2,
+                     uint64_t count_per_light, uint32_t max_depth, rtg_photon *out, uint64_t capacity, uint64_t *n_photons);
+int orc_indirect_irrad(const orc_scene *s, const orc_kd *kd, const rtg_photon *photons, const rtg_point *points,
+                       uint64_t n_points, uint32_t photon_samples, uint32_t newton_steps, double newton_epsilon,
+                       uint32_t max_depth, double *rgb_out, int threads);
+void orc_photon_adjust(const orc_scene *s, const rtg_photon *ph, const rtg_point *p, uint32_t newton_steps, uint32_t max_depth,
+                       double *out12, double *out_seps);
+
 #ifdef __cplusplus
 }
 #endif

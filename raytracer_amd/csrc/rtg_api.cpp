@@ -366,6 +366,27 @@ int api_fail(rtg_ctx *ctx, int code, const char *fmt, ...) {
     return code;
 }
 bool api_is_device_pointer(const void *p) { return is_device_pointer(p); }
+int api_scratch(rtg_ctx *ctx, const char *name, size_t bytes, void **out) { return scratch_get(ctx, name, bytes, out); }
+int api_input(rtg_ctx *ctx, const char *name, const void *user, size_t bytes, const void **dev) {
+    return in_prepare(ctx, name, user, bytes, dev);
+}
+int api_bind_scene(rtg_scene *scene) { return check_scene_call(scene); }
+int api_trace_device(rtg_scene *scene, const double *d_rays6, uint64_t n, rtg_hit *d_hits) {
+    rtg_ctx *ctx = scene->ctx;
+    if (n == 0) return RTG_OK;
+    if (n > 0xFFFFFFFFull) return fail(ctx, RTG_E_LIMIT, "more than 2^32-1 rays in one launch (split the call)");
+    int rc;
+    DevScene ds;
+    if ((rc = scene_for_launch(scene, (n + kBlock - 1) / kBlock * kBlock, ds)) != RTG_OK) return rc;
+    if (ctx->traversal == 2) {
+        PhasedScratch ps;
+        if ((rc = phased_scratch(ctx, ds, n, ps)) != RTG_OK) return rc;
+        HIP_TRY(ctx, launch_trace_phased(ctx->stream, ds, d_rays6, n, ps, ctx->tune, d_hits, nullptr));
+    } else {
+        HIP_TRY(ctx, launch_trace(ctx->stream, ds, d_rays6, n, d_hits, nullptr, nullptr));
+    }
+    return RTG_OK;
+}
 } // namespace rtg
 
 extern "C" {
@@ -1008,6 +1029,10 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
     s->ctx = ctx;
     s->device = ctx->device;
     s->max_depth = max_depth;
+    s->object_leaves.assign(desc->n_objects, 0);
+    for (uint32_t i = 0; i < desc->n_objects; i++)
+        if (desc->objects[i].kind == RTG_MESH || desc->objects[i].kind == RTG_PATCHES)
+            s->object_leaves[i] = desc->objects[i].mesh->n_leaves;
     rc = upload(ctx, objs.data(), objs.size() * sizeof(DevObject), &s->d_objects);
     if (rc != RTG_OK) {
         delete s;

@@ -55,6 +55,7 @@ struct rtg_scene {
     bool any_dielectric = false;   // some material refracts: frames need the specular path tree
     bool has_mesh = false;         // some object is a mesh or patch set: shading is worth doing as passes of the
                                    // persistent kernel (sphere/plane-only scenes are cheaper in one fused launch)
+    std::vector<uint64_t> object_leaves;   // per object: triangles of its mesh (0 for spheres and planes)
 };
 
 
@@ -63,4 +64,13 @@ namespace rtg {
 int api_fail(rtg_ctx *ctx, int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
 // True when `p` can be dereferenced by a kernel on the current device.
 bool api_is_device_pointer(const void *p);
+// A named device buffer of the context, grown on demand and kept for the next call.
+int api_scratch(rtg_ctx *ctx, const char *name, size_t bytes, void **out);
+// Device view of an input: a device pointer as it is, host memory uploaded into the named scratch buffer.
+int api_input(rtg_ctx *ctx, const char *name, const void *user, size_t bytes, const void **dev);
+// Makes the scene's GPU current; RTG_E_INVALID for a null scene.
+int api_bind_scene(rtg_scene *scene);
+// Closest hits of `n` device-resident rays into device memory, through the context's traversal (what rtg_trace
+// does between its input and output staging); asynchronous on the context's stream.
+int api_trace_device(rtg_scene *scene, const double *d_rays6, uint64_t n, rtg_hit *d_hits);
 } // namespace rtg

@@ -123,6 +123,36 @@ hipError_t launch_ray_sort(hipStream_t stream, const double *rays6, uint64_t n, 
 hipError_t launch_ray_unsort(hipStream_t stream, const rtg_hit *hits, const rtg_ray_counters *counters, const uint32_t *perm,
                              uint64_t n, rtg_hit *out_hits, rtg_ray_counters *out_counters);
 
+// The photon map (rtg_photon.hip).  `nodes` is the k-d tree as 80-byte records in implicit-median order (written by
+// the host build in rtg_photon_api.cpp); k <= 16.
+hipError_t launch_kd_nearest(hipStream_t stream, const void *nodes, uint32_t n_nodes, const double *queries3,
+                             uint64_t n_queries, uint32_t k, uint32_t *out_index, double *out_distance);
+// Photons of one batch of path records: flags + exclusive scan (offsets[i] = photons before path i) + records
+// written at out[offsets[i]] while that is below `room`.
+size_t photon_scan_temp_bytes(uint32_t n);
+hipError_t launch_photons_from_paths(hipStream_t stream, const rtg_path *paths, uint32_t n_paths, const double *dirs2,
+                                     const rtg_light *lights, uint64_t first_ray, uint64_t count_per_light, uint32_t *flags,
+                                     uint32_t *offsets, void *temp, size_t temp_bytes, uint64_t room, rtg_photon *out);
+// The (surface point, photon sample) pairs the caustic correction works on; pair e = point * samples + sample.
+struct PhotonPairs {
+    const DevObject *objects = nullptr;
+    uint32_t n_objects = 0;
+    const uint64_t *object_leaves = nullptr;
+    const rtg_photon *photons = nullptr;
+    uint32_t n_photons = 0;
+    const uint32_t *nearest = nullptr;
+    const rtg_point *points = nullptr;
+    uint64_t n_points = 0;
+    uint32_t samples = 0;
+};
+hipError_t launch_photon_newton(hipStream_t stream, const PhotonPairs &p, uint32_t newton_steps, double *dir2);
+hipError_t launch_photon_final_start(hipStream_t stream, const PhotonPairs &p, const double *dir2, double *state, double *rays6,
+                                     uint32_t *status);
+hipError_t launch_photon_final_bounce(hipStream_t stream, const PhotonPairs &p, uint32_t level, const rtg_hit *hits, double *state,
+                                      double *rays6, uint32_t *status, double *landing);
+hipError_t launch_photon_sum(hipStream_t stream, const PhotonPairs &p, const uint32_t *status, const double *landing,
+                             double newton_epsilon, double *rgb);
+
 // Looks up this GPU's copy of the fixed scratch array behind rtg_render_primary_static (rtg_static.hip); called
 // with `device` current, once per device (later calls return at once).
 hipError_t static_scratch_init(int device);

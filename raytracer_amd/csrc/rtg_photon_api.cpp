@@ -1,0 +1,382 @@
+// rtg_photon_api.cpp -- the photon-map entry points of include/rtg.h: the photon pass, the k-d tree, nearest
+// photons and the caustic term of a surface point (src/render/renderer.rs:116-138, 206-265; src/tree/kd_tree.rs).
+//
+// Host-side duties only.  The photon pass turns the caller's emission directions into rays with the host's libm
+// (as the reference does) and hands them to rtg_trace_paths in batches; the k-d tree is built here, on the host,
+// with the reference's own recipe (median split on the widest axis, implicit in the array order) and uploaded once.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "rtg_internal.hpp"
+#include "rtg_launch.hpp"
+
+using namespace rtg;
+
+struct rtg_photon_map {
+    rtg_ctx *ctx = nullptr;          // calls on the map run on this context: it must outlive the map's last call
+    int device = 0;
+    void *d_nodes = nullptr;         // k-d tree, 80 bytes per photon
+    void *d_photons = nullptr;       // the caller's records in the caller's order
+    uint64_t n = 0;
+    uint32_t max_bounces = 0;        // the longest photon path: levels the corrected photons need to be traced for
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                            \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            (void)hipGetLastError();                                                                  \
+            return api_fail(ctx, e_ == hipErrorOutOfMemory ? RTG_E_NOMEM : RTG_E_HIP, "%s: %s", #expr, \
+                            hipGetErrorString(e_));                                                   \
+        }                                                                                             \
+    } while (0)
+
+// sin and cos as two separate libm calls, as rustc emits them for `ZenithY::into_normal`; a compiler that merges
+// the pair into sincos() changes the last place of about one direction in a thousand (glibc).
+double (*volatile libm_sin)(double) = ::sin;
+double (*volatile libm_cos)(double) = ::cos;
+
+// One entry of the k-d tree as the kernel reads it (KdNode in rtg_photon.hip).
+struct alignas(16) HostKdNode {
+    double pos[3];
+    double lo[3], hi[3];
+    uint32_t value;
+    uint32_t axis;
+};
+static_assert(sizeof(HostKdNode) == 80, "k-d node must be 5 x 16 B");
+
+// f64::minimum / f64::maximum as Bounds::union uses them (src/geo/bounds.rs:28-33)
+double f_min(double a, double b) {
+    if (a != a) return a;
+    if (b != b) return b;
+    if (a < b) return a;
+    if (b < a) return b;
+    return std::signbit(a) ? a : b;
+}
+double f_max(double a, double b) {
+    if (a != a) return a;
+    if (b != b) return b;
+    if (a > b) return a;
+    if (b > a) return b;
+    return std::signbit(a) ? b : a;
+}
+struct Box {
+    double lo[3], hi[3];
+};
+Box box_empty() {
+    const double inf = std::numeric_limits<double>::infinity();
+    return Box{{inf, inf, inf}, {-inf, -inf, -inf}};
+}
+void box_add(Box &b, const Box &o) {
+    for (int i = 0; i < 3; i++) {
+        b.lo[i] = f_min(b.lo[i], o.lo[i]);
+        b.hi[i] = f_max(b.hi[i], o.hi[i]);
+    }
+}
+// KdTree::build_rec (src/tree/kd_tree.rs:79-95) over tree[0..len); subtrees large enough run on their own threads
+// down to `fork` levels.
+Box kd_build(HostKdNode *tree, size_t len, int fork) {
+    Box bounds = box_empty();
+    if (len == 0) return bounds;
+    for (size_t i = 0; i < len; i++)
+        for (int k = 0; k < 3; k++) {
+            bounds.lo[k] = f_min(bounds.lo[k], tree[i].pos[k]);
+            bounds.hi[k] = f_max(bounds.hi[k], tree[i].pos[k]);
+        }
+    int axis = 0;                           // max_by_key: the last of equal maxima
+    for (int i = 1; i < 3; i++)
+        if (!(bounds.hi[i] - bounds.lo[i] < bounds.hi[axis] - bounds.lo[axis])) axis = i;
+    const size_t center = len / 2;          // src/tree/seq_tree.rs:41
+    std::nth_element(tree, tree + center, tree + len,
+                     [axis](const HostKdNode &a, const HostKdNode &b) { return a.pos[axis] < b.pos[axis]; });
+    tree[center].axis = (uint32_t)axis;
+    Box left, right;
+    if (fork > 0 && len >= (size_t)1 << 16) {
+        std::thread t([&]() { left = kd_build(tree, center, fork - 1); });
+        right = kd_build(tree + center + 1, len - center - 1, fork - 1);
+        t.join();
+    } else {
+        left = kd_build(tree, center, 0);
+        right = kd_build(tree + center + 1, len - center - 1, 0);
+    }
+    Box b = box_empty();
+    box_add(b, left);
+    box_add(b, right);
+    Box self;
+    for (int k = 0; k < 3; k++) self.lo[k] = self.hi[k] = tree[center].pos[k];
+    box_add(b, self);
+    for (int k = 0; k < 3; k++) {
+        tree[center].lo[k] = b.lo[k];
+        tree[center].hi[k] = b.hi[k];
+    }
+    return b;
+}
+
+int check_map_call(rtg_photon_map *map) {
+    if (!map || !map->ctx) return api_fail(nullptr, RTG_E_INVALID, "null photon map");
+    hipError_t e = hipSetDevice(map->device);
+    if (e != hipSuccess) return api_fail(map->ctx, RTG_E_HIP, "hipSetDevice(%d): %s", map->device, hipGetErrorString(e));
+    return RTG_OK;
+}
+
+// copies `bytes` from device scratch to the caller's buffer (host or device) on the context's stream
+int copy_out(rtg_ctx *ctx, void *user, const void *dev, size_t bytes) {
+    if (bytes == 0) return RTG_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(user, dev, bytes, api_is_device_pointer(user) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                ctx->stream));
+    return RTG_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const double *dirs2,
+                     uint64_t count_per_light, uint32_t max_depth, rtg_photon *out_photons, uint64_t capacity,
+                     uint64_t *n_photons) {
+    int rc = api_bind_scene(scene);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = scene->ctx;
+    if (!n_photons) return api_fail(ctx, RTG_E_INVALID, "rtg_photons_emit: n_photons is null");
+    *n_photons = 0;
+    if (max_depth < 1 || max_depth > 4) return api_fail(ctx, RTG_E_INVALID, "rtg_photons_emit: max_depth must be 1..4");
+    const uint64_t n_rays = (uint64_t)n_lights * count_per_light;
+    if (n_rays == 0) return RTG_OK;
+    if (!lights || !dirs2) return api_fail(ctx, RTG_E_INVALID, "rtg_photons_emit: lights / dirs2 is null");
+    if (api_is_device_pointer(lights) || api_is_device_pointer(dirs2))
+        return api_fail(ctx, RTG_E_INVALID, "rtg_photons_emit: lights and dirs2 are host memory (the directions' sin / cos are taken on the host)");
+    if (capacity && !out_photons) return api_fail(ctx, RTG_E_INVALID, "rtg_photons_emit: out_photons is null");
+    if (count_per_light > (1ull << 40) || n_rays > (1ull << 40)) return api_fail(ctx, RTG_E_LIMIT, "rtg_photons_emit: too many directions");
+
+    const void *d_lights = nullptr;
+    if ((rc = api_input(ctx, "photon_lights", lights, (size_t)n_lights * sizeof(rtg_light), &d_lights)) != RTG_OK) return rc;
+    const uint64_t batch = 1ull << 18;                       // rays per rtg_trace_paths call
+    const uint64_t per_ray = (1ull << max_depth) - 1;        // paths a ray can have
+    std::vector<double> rays;
+    uint64_t total = 0;
+    for (uint64_t first = 0; first < n_rays; first += batch) {
+        const uint64_t m = std::min(batch, n_rays - first);
+        rays.resize((size_t)m * 6);
+        for (uint64_t i = 0; i < m; i++) {
+            const uint64_t r = first + i;
+            const rtg_light &light = lights[r / count_per_light];
+            // ZenithY::into_normal (src/geo/sphere.rs:29-34); Ray::new(light.sphere.orig(), ..) (renderer.rs:123)
+            const double zenith = dirs2[r * 2], y = dirs2[r * 2 + 1];
+            const double radius = std::sqrt(1.0 - y * y);
+            double *w = &rays[(size_t)i * 6];
+            w[0] = light.position[0];
+            w[1] = light.position[1];
+            w[2] = light.position[2];
+            w[3] = libm_cos(zenith) * radius;
+            w[4] = y;
+            w[5] = libm_sin(zenith) * radius;
+        }
+        void *d_paths = nullptr;
+        if ((rc = api_scratch(ctx, "photon_paths", (size_t)(m * per_ray) * sizeof(rtg_path), &d_paths)) != RTG_OK) return rc;
+        uint64_t n_paths = 0;
+        if ((rc = rtg_trace_paths(scene, rays.data(), m, max_depth, (rtg_path *)d_paths, m * per_ray, &n_paths)) != RTG_OK) return rc;
+        if (n_paths == 0) continue;
+        void *flags = nullptr, *offsets = nullptr, *temp = nullptr, *d_out = nullptr;
+        const void *d_dirs = nullptr;
+        const size_t temp_bytes = photon_scan_temp_bytes((uint32_t)n_paths);
+        if ((rc = api_scratch(ctx, "photon_flags", (size_t)n_paths * sizeof(uint32_t), &flags)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "photon_offsets", (size_t)n_paths * sizeof(uint32_t), &offsets)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "photon_scan_temp", temp_bytes, &temp)) != RTG_OK) return rc;
+        // a batch writes only what still fits the caller's room
+        const uint64_t room = capacity > total ? std::min<uint64_t>(capacity - total, n_paths) : 0;
+        if ((rc = api_scratch(ctx, "photon_out", (size_t)std::max<uint64_t>(room, 1) * sizeof(rtg_photon), &d_out)) != RTG_OK) return rc;
+        if ((rc = api_input(ctx, "photon_dirs", dirs2 + first * 2, (size_t)m * 2 * sizeof(double), &d_dirs)) != RTG_OK) return rc;
+        HIP_TRY(ctx, launch_photons_from_paths(ctx->stream, (const rtg_path *)d_paths, (uint32_t)n_paths, (const double *)d_dirs,
+                                               (const rtg_light *)d_lights, first, count_per_light, (uint32_t *)flags,
+                                               (uint32_t *)offsets, temp, temp_bytes, room, (rtg_photon *)d_out));
+        uint32_t last[2] = {0, 0};                           // offsets[n - 1], flags[n - 1]
+        HIP_TRY(ctx, hipMemcpyAsync(&last[0], (const uint32_t *)offsets + (n_paths - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&last[1], (const uint32_t *)flags + (n_paths - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const uint64_t made = (uint64_t)last[0] + last[1];
+        if (total + made <= capacity) {
+            if ((rc = copy_out(ctx, out_photons + total, d_out, (size_t)made * sizeof(rtg_photon))) != RTG_OK) return rc;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the scratch is reused by the next batch
+        }
+        total += made;
+    }
+    *n_photons = total;
+    if (total > capacity)
+        return api_fail(ctx, RTG_E_LIMIT, "rtg_photons_emit: %llu photons, room for %llu", (unsigned long long)total,
+                        (unsigned long long)capacity);
+    return RTG_OK;
+}
+
+int rtg_photon_map_create(rtg_ctx *ctx, const rtg_photon *photons, uint64_t n_photons, rtg_photon_map **out) {
+    if (!ctx) return api_fail(nullptr, RTG_E_INVALID, "null ctx");
+    if (!out) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_create: out is null");
+    *out = nullptr;
+    if (n_photons && !photons) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_create: photons is null");
+    if (n_photons >= (1ull << 31)) return api_fail(ctx, RTG_E_LIMIT, "rtg_photon_map_create: at most 2^31 - 1 photons");
+    if (api_is_device_pointer(photons)) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_create: photons is host memory");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<HostKdNode> tree;
+    try {
+        tree.resize((size_t)n_photons);
+    } catch (const std::bad_alloc &) {
+        return api_fail(ctx, RTG_E_NOMEM, "out of host memory");
+    }
+    uint32_t max_bounces = 0;
+    for (uint64_t i = 0; i < n_photons; i++) {
+        HostKdNode &k = tree[(size_t)i];
+        for (int c = 0; c < 3; c++) {
+            k.pos[c] = photons[i].position[c];
+            // the reference refuses NaN keys (NotNan::try_from(..).unwrap(), src/tree/kd_tree.rs:81-82)
+            if (k.pos[c] != k.pos[c]) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_create: photon %llu has a NaN position", (unsigned long long)i);
+            k.lo[c] = k.hi[c] = std::numeric_limits<double>::quiet_NaN();
+        }
+        k.value = (uint32_t)i;
+        k.axis = 0;
+        max_bounces = std::max(max_bounces, std::min(photons[i].n_bounces, 3u));
+    }
+    kd_build(tree.data(), tree.size(), 3);
+    rtg_photon_map *m = new (std::nothrow) rtg_photon_map();
+    if (!m) return api_fail(ctx, RTG_E_NOMEM, "out of host memory");
+    m->ctx = ctx;
+    m->device = ctx->device;
+    m->n = n_photons;
+    m->max_bounces = max_bounces;
+    if (n_photons) {
+        hipError_t e = hipMalloc(&m->d_nodes, tree.size() * sizeof(HostKdNode));
+        if (e == hipSuccess) e = hipMalloc(&m->d_photons, (size_t)n_photons * sizeof(rtg_photon));
+        if (e == hipSuccess) e = hipMemcpy(m->d_nodes, tree.data(), tree.size() * sizeof(HostKdNode), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(m->d_photons, photons, (size_t)n_photons * sizeof(rtg_photon), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            rtg_photon_map_destroy(m);
+            return api_fail(ctx, e == hipErrorOutOfMemory ? RTG_E_NOMEM : RTG_E_HIP, "rtg_photon_map_create: %s", hipGetErrorString(e));
+        }
+    }
+    *out = m;
+    return RTG_OK;
+}
+
+void rtg_photon_map_destroy(rtg_photon_map *map) {
+    if (!map) return;
+    (void)hipSetDevice(map->device);
+    if (map->d_nodes) (void)hipFree(map->d_nodes);
+    if (map->d_photons) (void)hipFree(map->d_photons);
+    delete map;
+}
+
+int rtg_photon_map_nearest(rtg_photon_map *map, const double *queries3, uint64_t n_queries, uint32_t k, uint32_t *out_index,
+                           double *out_distance) {
+    int rc = check_map_call(map);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = map->ctx;
+    if (k > 16) return api_fail(ctx, RTG_E_LIMIT, "rtg_photon_map_nearest: k is at most 16");
+    if (n_queries == 0 || k == 0) return RTG_OK;
+    if (!queries3) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_nearest: queries3 is null");
+    if (!out_index && !out_distance) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_nearest: no output requested");
+    if (n_queries > 0xFFFFFFFFull / 16) return api_fail(ctx, RTG_E_LIMIT, "rtg_photon_map_nearest: too many queries for one call");
+    const void *d_q = nullptr;
+    if ((rc = api_input(ctx, "kd_queries", queries3, (size_t)n_queries * 3 * sizeof(double), &d_q)) != RTG_OK) return rc;
+    const size_t slots = (size_t)n_queries * k;
+    void *d_i = nullptr, *d_d = nullptr;
+    const bool i_dev = out_index && api_is_device_pointer(out_index), d_dev = out_distance && api_is_device_pointer(out_distance);
+    if (i_dev)
+        d_i = out_index;
+    else if ((rc = api_scratch(ctx, "kd_index", slots * sizeof(uint32_t), &d_i)) != RTG_OK)
+        return rc;
+    if (d_dev)
+        d_d = out_distance;
+    else if ((rc = api_scratch(ctx, "kd_distance", slots * sizeof(double), &d_d)) != RTG_OK)
+        return rc;
+    HIP_TRY(ctx, launch_kd_nearest(ctx->stream, map->d_nodes, (uint32_t)map->n, (const double *)d_q, n_queries, k, (uint32_t *)d_i,
+                                   (double *)d_d));
+    bool staged = false;
+    if (out_index && !i_dev) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_index, d_i, slots * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        staged = true;
+    }
+    if (out_distance && !d_dev) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_distance, d_d, slots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        staged = true;
+    }
+    if (staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTG_OK;
+}
+
+int rtg_indirect_irrad(rtg_scene *scene, rtg_photon_map *map, const rtg_point *points, uint64_t n_points, uint32_t photon_samples,
+                       uint32_t newton_steps, double newton_epsilon, double *rgb_out) {
+    int rc = api_bind_scene(scene);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = scene->ctx;
+    if (!map) return api_fail(ctx, RTG_E_INVALID, "rtg_indirect_irrad: map is null");
+    if (map->device != scene->device) return api_fail(ctx, RTG_E_INVALID, "rtg_indirect_irrad: the photon map lives on another GPU");
+    if (photon_samples > 16) return api_fail(ctx, RTG_E_LIMIT, "rtg_indirect_irrad: photon_samples is at most 16");
+    if (scene->dev.has_patches) return api_fail(ctx, RTG_E_UNSUPPORTED, "rtg_indirect_irrad: scenes with patch sets are not supported");
+    if (n_points == 0) return RTG_OK;
+    if (!points || !rgb_out) return api_fail(ctx, RTG_E_INVALID, "rtg_indirect_irrad: points / rgb_out is null");
+    const uint64_t n_pairs = n_points * photon_samples;
+    if (n_pairs > 0xFFFFFFFFull) return api_fail(ctx, RTG_E_LIMIT, "rtg_indirect_irrad: more than 2^32-1 (point, sample) pairs in one call");
+
+    const void *d_points = nullptr;
+    if ((rc = api_input(ctx, "irrad_points", points, (size_t)n_points * sizeof(rtg_point), &d_points)) != RTG_OK) return rc;
+    const bool out_dev = api_is_device_pointer(rgb_out);
+    void *d_rgb = rgb_out;
+    if (!out_dev && (rc = api_scratch(ctx, "irrad_rgb", (size_t)n_points * 3 * sizeof(double), &d_rgb)) != RTG_OK) return rc;
+    if (photon_samples == 0 || map->n == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(d_rgb, 0, (size_t)n_points * 3 * sizeof(double), ctx->stream));
+    } else {
+        void *queries = nullptr, *nearest = nullptr, *dist = nullptr, *dir2 = nullptr, *state = nullptr, *rays = nullptr, *hits = nullptr,
+             *status = nullptr, *landing = nullptr, *leaves = nullptr;
+        if ((rc = api_scratch(ctx, "irrad_queries", (size_t)n_points * 3 * sizeof(double), &queries)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "irrad_nearest", (size_t)n_pairs * sizeof(uint32_t), &nearest)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "irrad_distance", (size_t)n_pairs * sizeof(double), &dist)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "irrad_dir", (size_t)n_pairs * 2 * sizeof(double), &dir2)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "irrad_state", (size_t)n_pairs * 18 * sizeof(double), &state)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "irrad_rays", (size_t)n_pairs * 6 * sizeof(double), &rays)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "irrad_hits", (size_t)n_pairs * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "irrad_status", (size_t)n_pairs * sizeof(uint32_t), &status)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "irrad_landing", (size_t)n_pairs * 9 * sizeof(double), &landing)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "irrad_leaves", std::max<size_t>(1, scene->object_leaves.size()) * sizeof(uint64_t), &leaves)) != RTG_OK)
+            return rc;
+        if (!scene->object_leaves.empty())
+            HIP_TRY(ctx, hipMemcpyAsync(leaves, scene->object_leaves.data(), scene->object_leaves.size() * sizeof(uint64_t),
+                                        hipMemcpyHostToDevice, ctx->stream));
+        // the points' positions are the queries: a strided copy out of the point records
+        HIP_TRY(ctx, hipMemcpy2DAsync(queries, 3 * sizeof(double), (const char *)d_points + offsetof(rtg_point, position),
+                                      sizeof(rtg_point), 3 * sizeof(double), (size_t)n_points, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx, launch_kd_nearest(ctx->stream, map->d_nodes, (uint32_t)map->n, (const double *)queries, n_points, photon_samples,
+                                       (uint32_t *)nearest, (double *)dist));
+        PhotonPairs pr;
+        pr.objects = scene->dev.objects;
+        pr.n_objects = scene->dev.n_objects;
+        pr.object_leaves = (const uint64_t *)leaves;
+        pr.photons = (const rtg_photon *)map->d_photons;
+        pr.n_photons = (uint32_t)map->n;
+        pr.nearest = (const uint32_t *)nearest;
+        pr.points = (const rtg_point *)d_points;
+        pr.n_points = n_points;
+        pr.samples = photon_samples;
+        HIP_TRY(ctx, launch_photon_newton(ctx->stream, pr, newton_steps, (double *)dir2));
+        HIP_TRY(ctx, launch_photon_final_start(ctx->stream, pr, (const double *)dir2, (double *)state, (double *)rays, (uint32_t *)status));
+        for (uint32_t level = 0; level <= map->max_bounces; level++) {   // a photon lands after its last bounce
+            if ((rc = api_trace_device(scene, (const double *)rays, n_pairs, (rtg_hit *)hits)) != RTG_OK) return rc;
+            HIP_TRY(ctx, launch_photon_final_bounce(ctx->stream, pr, level, (const rtg_hit *)hits, (double *)state, (double *)rays,
+                                                    (uint32_t *)status, (double *)landing));
+        }
+        HIP_TRY(ctx, launch_photon_sum(ctx->stream, pr, (const uint32_t *)status, (const double *)landing, newton_epsilon, (double *)d_rgb));
+    }
+    if (!out_dev) {
+        HIP_TRY(ctx, hipMemcpyAsync(rgb_out, d_rgb, (size_t)n_points * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return RTG_OK;
+}
+
+} // extern "C"

@@ -121,6 +121,7 @@ uint64_t rth_to_hdr(const double *rgb, uint32_t width, uint32_t height, uint8_t 
     return b.size();
 }
 void rth_fibonacci_sphere(uint64_t count, uint64_t seed, double *dirs3) { rt::fibonacci_sphere(count, seed, dirs3); }
+void rth_fibonacci_zenith_y(uint64_t count, uint64_t seed, double *dirs2) { rt::fibonacci_zenith_y(count, seed, dirs2); }
 uint64_t rth_images_tar(const double *rgb, uint32_t width, uint32_t height, double seconds, uint8_t *out, uint64_t cap) {
     std::map<std::string, std::vector<uint8_t>> images;                    // Renderer::images (renderer.rs:379-385)
     const size_t n = (size_t)width * height * 3;

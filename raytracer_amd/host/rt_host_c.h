@@ -22,6 +22,7 @@ uint32_t rth_bvh_depth(const rth_bvh *b);
 void rth_heightfield(uint32_t nx, uint32_t ny, uint64_t seed, double scale, rtg_tri *out);
 /* Sphere::fibonacci_sphere + ZenithY::into_normal (src/geo/sphere.rs:27-32,48-80): the photon pass's directions. */
 void rth_fibonacci_sphere(uint64_t count, uint64_t seed, double *dirs3);
+void rth_fibonacci_zenith_y(uint64_t count, uint64_t seed, double *dirs2);
 void rth_bench_mesh_rays(const double lo_hi[6], uint64_t n, uint64_t seed, double *rays6);
 /* Stable sort of rays by (direction octant, Morton code of origin); perm[i] = source index of sorted ray i. */
 void rth_sort_rays(const double lo_hi[6], const double *rays6, uint64_t n, uint32_t *perm, double *sorted_rays6);

@@ -94,6 +94,11 @@ void bench_mesh_rays(const double b[6], uint64_t n, uint64_t seed, double *rays6
 // zenith (phi * (i + u)) mod 2 pi and height -1 + dydi * (i + u) + dydj * v, with u, v in [0, 1) drawn per
 // direction.  The reference draws them from an entropy-seeded generator (renderer.rs:112), so no two of its runs
 // agree; here they come from the seeded SplitMix64 stream used by the other generators.
+// sin and cos as two separate libm calls (what rustc emits); merged into sincos() they round differently in the
+// last place for about one argument in a thousand.
+static double (*volatile libm_sin)(double) = ::sin;
+static double (*volatile libm_cos)(double) = ::cos;
+
 void fibonacci_sphere(uint64_t count, uint64_t seed, double *dirs3) {
     const double pi = 3.14159265358979323846264338327950288;
     const double n = (double)count;
@@ -109,9 +114,28 @@ void fibonacci_sphere(uint64_t count, uint64_t seed, double *dirs3) {
         double zenith = std::fmod(phi * i, 2.0 * pi);
         double y = -1.0 + dydi * i + dydj * j;
         double radius = std::sqrt(1.0 - y * y);
-        dirs3[k * 3 + 0] = std::cos(zenith) * radius;
+        dirs3[k * 3 + 0] = libm_cos(zenith) * radius;
         dirs3[k * 3 + 1] = y;
-        dirs3[k * 3 + 2] = std::sin(zenith) * radius;
+        dirs3[k * 3 + 2] = libm_sin(zenith) * radius;
+    }
+}
+
+// The same draws as fibonacci_sphere, left as `ZenithY` (zenith, y) pairs: what the photon pass stores per photon
+// and corrects later (src/geo/sphere.rs:52-80, src/render/renderer.rs:116-118).
+void fibonacci_zenith_y(uint64_t count, uint64_t seed, double *dirs2) {
+    const double pi = 3.14159265358979323846264338327950288;
+    const double n = (double)count;
+    const double phi = pi * (3.0 - std::sqrt(5.0));
+    const double d = 2.0 * pi / phi;
+    const double dydi = 2.0 / (n + d);
+    const double dydj = dydi * d;
+    uint64_t s = seed;
+    auto uni = [&s]() { return (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0); };
+    for (uint64_t k = 0; k < count; k++) {
+        double i = (double)k + uni();
+        double j = uni();
+        dirs2[k * 2 + 0] = std::fmod(phi * i, 2.0 * pi);
+        dirs2[k * 2 + 1] = -1.0 + dydi * i + dydj * j;
     }
 }
 

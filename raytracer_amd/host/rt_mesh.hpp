@@ -26,6 +26,7 @@ void bench_mesh_rays(const double lo_hi[6], uint64_t n, uint64_t seed, double *r
 // Photon directions: Sphere::fibonacci_sphere + ZenithY::into_normal (src/geo/sphere.rs:27-32,48-80), `count`
 // unit vectors (3 doubles each) with the per-direction jitter drawn from a seeded stream.
 void fibonacci_sphere(uint64_t count, uint64_t seed, double *dirs3);
+void fibonacci_zenith_y(uint64_t count, uint64_t seed, double *dirs2);
 
 // 30-bit Morton code of the origin inside lo_hi, with the direction octant in
 // the three top bits: the sort key used to make a ray batch wave-coherent.

@@ -164,8 +164,11 @@ View SceneBuilder::view() const {                              // lib.rs:87-89
 }
 std::vector<Light> SceneBuilder::lights() const {              // lib.rs:90-102
     const double lightz = 1.0, intensity = 100.0, lightdis = 1.0;
-    const double c = std::cos((double)time / 100.0 * PI * 2.0);
-    const double s = std::sin((double)time / 100.0 * PI * 2.0);
+    // two separate libm calls, as rustc emits them (a merged sincos() can round differently in the last place)
+    static double (*volatile libm_sin)(double) = ::sin;
+    static double (*volatile libm_cos)(double) = ::cos;
+    const double c = libm_cos((double)time / 100.0 * PI * 2.0);
+    const double s = libm_sin((double)time / 100.0 * PI * 2.0);
     return {Light{Sphere{Vec3{lightdis * c, lightdis * s, lightz}, 1.0}, Color{0.0, 0.0, intensity}},
             Light{Sphere{Vec3{-lightdis * c, lightdis * s, lightz}, 1.0}, Color{0.0, intensity, 0.0}}};
 }

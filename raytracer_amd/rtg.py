@@ -97,6 +97,10 @@ PATH_DTYPE = np.dtype([("ray", "<u4"), ("depth", "<u4"), ("modes", "<u4"), ("par
 COUNTER_DTYPE = np.dtype([("nodes_visited", "<u4"), ("tris_tested", "<u4")])
 PATCH_LEAF_DTYPE = np.dtype([("tu", "<f8", (3, 2)), ("patch", "<u4"), ("_pad", "<u4")])
 LIGHT_DTYPE = np.dtype([("position", "<f8", 3), ("color", "<f8", 3)])
+PHOTON_DTYPE = np.dtype([("position", "<f8", 3), ("origin", "<f8", 3), ("dir", "<f8", 2), ("light", "<f8", 3),
+                         ("surface_object", "<u4", 3), ("surface_leaf", "<u4", 3), ("n_bounces", "<u4"),
+                         ("modes", "<u4"), ("light_index", "<u4"), ("_pad", "<u4")])
+assert PHOTON_DTYPE.itemsize == 128
 assert NODE_DTYPE.itemsize == 64 and HIT_DTYPE.itemsize == 16 and POINT_DTYPE.itemsize == 112
 assert C.sizeof(BvhNode) == 64 and C.sizeof(Transform) == 328 and C.sizeof(Material) == 48
 
@@ -143,6 +147,11 @@ _sig(lib.rtg_trace_paths, C.c_int, _vp, _vp, C.c_uint64, C.c_uint32, _vp, C.c_ui
 _sig(lib.rtg_shade_direct, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, _vp, _vp)
 _sig(lib.rtg_render_frame, C.c_int, _vp, C.POINTER(View), _vp, C.c_uint32, C.c_uint32, C.c_uint32, Rect,
      C.c_uint32, _vp, _vp, _vp)
+_sig(lib.rtg_photons_emit, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64))
+_sig(lib.rtg_photon_map_create, C.c_int, _vp, _vp, C.c_uint64, C.POINTER(_vp))
+_sig(lib.rtg_photon_map_destroy, None, _vp)
+_sig(lib.rtg_photon_map_nearest, C.c_int, _vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp)
+_sig(lib.rtg_indirect_irrad, C.c_int, _vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, _vp)
 
 _sig(lib.rtg_comm_unique_id, C.c_int, _vp)
 _sig(lib.rtg_comm_create, C.c_int, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp))
@@ -158,6 +167,7 @@ _sig(host.rth_bvh_leaf_source, C.POINTER(C.c_uint32), _vp)
 _sig(host.rth_bvh_depth, C.c_uint32, _vp)
 _sig(host.rth_heightfield, None, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, _vp)
 _sig(host.rth_fibonacci_sphere, None, C.c_uint64, C.c_uint64, _vp)
+_sig(host.rth_fibonacci_zenith_y, None, C.c_uint64, C.c_uint64, _vp)
 _sig(host.rth_bench_mesh_rays, None, C.POINTER(C.c_double), C.c_uint64, C.c_uint64, _vp)
 _sig(host.rth_sort_rays, None, C.POINTER(C.c_double), _vp, C.c_uint64, _vp, _vp)
 _sig(host.rth_trispline_from_normal_hermite, None, _vp, _vp)
@@ -254,6 +264,13 @@ def fibonacci_sphere(count, seed=1):
     """Sphere::fibonacci_sphere + into_normal: (count, 3) unit directions for the photon pass."""
     out = np.empty((count, 3), dtype=np.float64)
     host.rth_fibonacci_sphere(count, seed, _ptr(out))
+    return out
+
+
+def fibonacci_zenith_y(count, seed=1):
+    """Sphere::fibonacci_sphere as the photon pass consumes it: (count, 2) `ZenithY` (zenith, y) pairs."""
+    out = np.empty((count, 2), dtype=np.float64)
+    host.rth_fibonacci_zenith_y(count, seed, _ptr(out))
     return out
 
 
@@ -513,6 +530,40 @@ class Comm:
             pass
 
 
+class PhotonMap:
+    """KdTree<Photon> on the GPU: nearest photons of a batch of points; handed to Scene.indirect_irrad."""
+    _h = None
+
+    def __init__(self, ctx, photons):
+        self.photons = np.ascontiguousarray(photons, dtype=PHOTON_DTYPE)
+        h = _vp()
+        ctx._check(lib.rtg_photon_map_create(ctx._h, _ptr(self.photons) if self.photons.shape[0] else None,
+                                             self.photons.shape[0], C.byref(h)))
+        self._h, self.ctx = h, ctx
+        ctx._scenes.add(self)              # closed before the context, like a scene
+
+    def nearest(self, queries3, k):
+        q = np.ascontiguousarray(queries3, dtype=np.float64).reshape(-1, 3)
+        idx = np.empty((q.shape[0], k), dtype=np.uint32)
+        dist = np.empty((q.shape[0], k), dtype=np.float64)
+        self.ctx._check(lib.rtg_photon_map_nearest(self._h, _ptr(q), q.shape[0], k, _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def nearest_raw(self, queries_ptr, n, k, index_ptr, distance_ptr):
+        self.ctx._check(lib.rtg_photon_map_nearest(self._h, _ptr(queries_ptr), n, k, _ptr(index_ptr), _ptr(distance_ptr)))
+
+    def close(self):
+        if self._h:
+            lib.rtg_photon_map_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown
+            pass
+
+
 class Mesh:
     _h = None
 
@@ -719,6 +770,30 @@ class Scene:
         self.ctx._check(lib.rtg_render_frame(self._h, C.byref(view), _ptr(lights), lights.shape[0], width, height,
                                              Rect(x0, y0, w, h), max_depth, _ptr(rgb), _ptr(c8), _ptr(hh)))
         return rgb, c8, hh
+
+    def photons_emit(self, lights, dirs2, max_depth=4, capacity=None):
+        """The photon pass: dirs2 is (n_lights, count, 2) `ZenithY` directions; PHOTON_DTYPE records in path order."""
+        lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+        dirs2 = np.ascontiguousarray(dirs2, dtype=np.float64).reshape(lights.shape[0], -1, 2)
+        if capacity is None:
+            capacity = dirs2.shape[0] * dirs2.shape[1] * ((1 << max_depth) - 1)
+        out = np.zeros(max(capacity, 1), dtype=PHOTON_DTYPE)
+        count = C.c_uint64()
+        self.ctx._check(lib.rtg_photons_emit(self._h, _ptr(lights), lights.shape[0], _ptr(dirs2), dirs2.shape[1], max_depth,
+                                             _ptr(out) if capacity else None, capacity, C.byref(count)))
+        return out[:count.value].copy()
+
+    def indirect_irrad(self, photon_map, points, photon_samples=3, newton_steps=5, newton_epsilon=1e-5):
+        """compute_indirect_irrad per point: (n, 3) float64."""
+        points = np.ascontiguousarray(points, dtype=POINT_DTYPE)
+        rgb = np.empty((points.shape[0], 3), dtype=np.float64)
+        self.ctx._check(lib.rtg_indirect_irrad(self._h, photon_map._h, _ptr(points), points.shape[0], photon_samples,
+                                               newton_steps, float(newton_epsilon), _ptr(rgb)))
+        return rgb
+
+    def indirect_irrad_raw(self, photon_map, points_ptr, n, photon_samples, newton_steps, newton_epsilon, rgb_ptr):
+        self.ctx._check(lib.rtg_indirect_irrad(self._h, photon_map._h, _ptr(points_ptr), n, photon_samples, newton_steps,
+                                               float(newton_epsilon), _ptr(rgb_ptr)))
 
     def render_frame_raw(self, view, lights_ptr, n_lights, width, height, tile, max_depth, rgb_ptr, rgba8_ptr, hits_ptr):
         self.ctx._check(lib.rtg_render_frame(self._h, C.byref(view), _ptr(lights_ptr), n_lights, width, height,

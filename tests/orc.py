@@ -73,6 +73,19 @@ _sig(lib.orc_trace_paths, C.c_int, _vp, _vp, C.c_uint64, C.c_uint32, _vp, C.c_ui
 _sig(lib.orc_shade_direct, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, _vp, _vp, C.c_int)
 _sig(lib.orc_render_frame, C.c_int, _vp, C.POINTER(rtg.View), _vp, C.c_uint32, C.c_uint32, C.c_uint32, rtg.Rect,
      C.c_uint32, _vp, _vp, _vp, C.c_int)
+_sig(lib.orc_der2_op, None, C.c_int, _dp, _dp, _dp)
+_sig(lib.orc_der2_partial_cmp, C.c_int, _dp, _dp)
+_sig(lib.orc_der2_known_answer, None, _dp)
+_sig(lib.orc_zenith_y_into_normal, None, _dp, _dp)
+_sig(lib.orc_fibonacci_sphere, None, C.c_uint64, _vp, _vp)
+_sig(lib.orc_kd_create, _vp, _vp, C.c_uint64)
+_sig(lib.orc_kd_destroy, None, _vp)
+_sig(lib.orc_kd_check, C.c_int, _vp)
+_sig(lib.orc_kd_nearest, None, _vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp, C.c_int)
+_sig(lib.orc_kd_nearest_brute, None, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint32, _vp, _vp, C.c_int)
+_sig(lib.orc_photons_emit, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64))
+_sig(lib.orc_indirect_irrad, C.c_int, _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, _vp, C.c_int)
+_sig(lib.orc_photon_adjust, None, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp)
 
 THREADS = min(8, os.cpu_count() or 1)
 
@@ -160,6 +173,81 @@ def patches_tessellate(patches, k):
     info = np.zeros(n, dtype=rtg.PATCH_LEAF_DTYPE)
     lib.orc_patches_tessellate(patches.ctypes.data, patches.shape[0], k, tris.ctypes.data, info.ctypes.data)
     return tris, info
+
+
+DER2_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "neg": 4, "sqrt": 5, "sin": 6, "cos": 7, "abs": 8, "minimum": 9,
+            "maximum": 10}
+
+
+def der2(op, a, b=(0.0, 0.0, 0.0)):
+    """One Der<2> operation on (v, d0, d1) triples."""
+    out = (C.c_double * 3)()
+    lib.orc_der2_op(DER2_OPS[op], d(a), d(b), out)
+    return np.array(list(out))
+
+
+def der2_partial_cmp(a, b):
+    """-1 / 0 / 1, or None when the derived PartialOrd gives no order."""
+    c = lib.orc_der2_partial_cmp(d(a), d(b))
+    return None if c == 2 else c
+
+
+def zenith_y_into_normal(dir2):
+    out = (C.c_double * 3)()
+    lib.orc_zenith_y_into_normal(d(dir2), out)
+    return np.array(list(out))
+
+
+def fibonacci_zenith_y(count, seed=1):
+    """Sphere::fibonacci_sphere with numpy's generator standing in for the reference's: (count, 2) ZenithY values."""
+    u = np.random.default_rng(seed).random((count, 2))
+    out = np.empty((count, 2), dtype=np.float64)
+    lib.orc_fibonacci_sphere(count, u.ctypes.data, out.ctypes.data)
+    return out
+
+
+class OracleKd:
+    """KdTree over positions; values are the positions' indices."""
+    _h = None
+
+    def __init__(self, positions3):
+        self.positions = np.ascontiguousarray(positions3, dtype=np.float64).reshape(-1, 3)
+        self._h = lib.orc_kd_create(self.positions.ctypes.data, self.positions.shape[0])
+
+    @property
+    def handle(self):
+        return self._h
+
+    def check(self):
+        return bool(lib.orc_kd_check(self._h))
+
+    def nearest(self, queries3, k, threads=THREADS):
+        q = np.ascontiguousarray(queries3, dtype=np.float64).reshape(-1, 3)
+        idx = np.empty((q.shape[0], k), dtype=np.uint32)
+        dist = np.empty((q.shape[0], k), dtype=np.float64)
+        if k:
+            lib.orc_kd_nearest(self._h, q.ctypes.data, q.shape[0], k, idx.ctypes.data, dist.ctypes.data, threads)
+        return idx, dist
+
+    def nearest_brute(self, queries3, k, threads=THREADS):
+        q = np.ascontiguousarray(queries3, dtype=np.float64).reshape(-1, 3)
+        idx = np.empty((q.shape[0], k), dtype=np.uint32)
+        dist = np.empty((q.shape[0], k), dtype=np.float64)
+        if k:
+            lib.orc_kd_nearest_brute(self.positions.ctypes.data, self.positions.shape[0], q.ctypes.data, q.shape[0], k,
+                                     idx.ctypes.data, dist.ctypes.data, threads)
+        return idx, dist
+
+    def close(self):
+        if self._h:
+            lib.orc_kd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown
+            pass
 
 
 class OracleBvh:
@@ -306,6 +394,36 @@ class OracleScene:
                              rtg.Rect(x0, y0, w, h), max_depth, rgb.ctypes.data, None if c8 is None else c8.ctypes.data,
                              None if hh is None else hh.ctypes.data, threads)
         return rgb, c8, hh
+
+    def photons_emit(self, lights, dirs2, max_depth=4):
+        """The photon pass with the directions supplied: dirs2 is (n_lights, count, 2)."""
+        lights = np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
+        dirs2 = np.ascontiguousarray(dirs2, dtype=np.float64).reshape(lights.shape[0], -1, 2)
+        cap = dirs2.shape[0] * dirs2.shape[1] * ((1 << max_depth) - 1)
+        out = np.zeros(max(cap, 1), dtype=rtg.PHOTON_DTYPE)
+        count = C.c_uint64()
+        lib.orc_photons_emit(self._h, lights.ctypes.data, lights.shape[0], dirs2.ctypes.data, dirs2.shape[1], max_depth,
+                             out.ctypes.data, cap, C.byref(count))
+        return out[:count.value].copy()
+
+    def indirect_irrad(self, kd, photons, points, photon_samples=3, newton_steps=5, newton_epsilon=1e-5, max_depth=4,
+                       threads=THREADS):
+        photons = np.ascontiguousarray(photons, dtype=rtg.PHOTON_DTYPE)
+        points = np.ascontiguousarray(points, dtype=rtg.POINT_DTYPE)
+        rgb = np.empty((points.shape[0], 3), dtype=np.float64)
+        lib.orc_indirect_irrad(self._h, kd.handle, photons.ctypes.data, points.ctypes.data, points.shape[0], photon_samples,
+                               newton_steps, float(newton_epsilon), max_depth, rgb.ctypes.data, threads)
+        return rgb
+
+    def photon_adjust(self, photon, point, newton_steps=5, max_depth=4):
+        """Newton iteration + final trace of one photon against one point (see orc_photon_adjust)."""
+        ph = np.ascontiguousarray(np.asarray(photon, dtype=rtg.PHOTON_DTYPE).reshape(1))
+        pt = np.ascontiguousarray(np.asarray(point, dtype=rtg.POINT_DTYPE).reshape(1))
+        out = np.empty(12, dtype=np.float64)
+        seps = np.empty(max(2 * newton_steps, 1), dtype=np.float64)
+        lib.orc_photon_adjust(self._h, ph.ctypes.data, pt.ctypes.data, newton_steps, max_depth, out.ctypes.data, seps.ctypes.data)
+        return {"dir": out[0:2], "landed": out[2] != 0.0, "position": out[3:6], "d0": out[6:9], "d1": out[9:12],
+                "seps": seps[:2 * newton_steps].reshape(-1, 2)}
 
     def close(self):
         if self._h:

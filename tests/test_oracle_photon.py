@@ -1,0 +1,209 @@
+"""The oracle's photon-map routines: Der<2>, the k-d tree, the photon pass and the caustic correction.
+
+Pinned by the reference's own tests: Der addition (src/math/scalar.rs:360-367) and `KdTree::nearest` against a
+brute-force sort (src/tree/kd_tree.rs:221-268).  Everything else is checked against independent evaluations
+(finite differences, a direct re-trace), because the reference holds no fixture for it."""
+import numpy as np
+import pytest
+
+from raytracer_amd import rtg
+
+import orc
+import scenes
+
+
+def test_der2_reference_known_answer():
+    out = (orc.C.c_double * 3)()
+    orc.lib.orc_der2_known_answer(out)
+    assert list(out) == [6.0, 1.0, 1.0]                      # Der { v: 6.0, d: [1.0, 1.0] }
+
+
+def test_der2_operations_agree_with_finite_differences():
+    rng = np.random.default_rng(3)
+    h = 1e-6
+
+    def f(op, x, y):
+        return {"add": x + y, "sub": x - y, "mul": x * y, "div": x / y, "neg": -x, "sqrt": np.sqrt(x), "sin": np.sin(x),
+                "cos": np.cos(x), "abs": abs(x)}[op]
+
+    for op in ("add", "sub", "mul", "div", "neg", "sqrt", "sin", "cos", "abs"):
+        for _ in range(20):
+            # x = x0 + a*s + b*t, y = y0 + c*s + e*t: a two-parameter family through (x0, y0)
+            x0, y0 = rng.uniform(0.5, 3.0, 2)
+            a, b, c, e = rng.uniform(-2, 2, 4)
+            got = orc.der2(op, (x0, a, b), (y0, c, e))
+            assert got[0] == f(op, x0, y0)
+            ds = (f(op, x0 + a * h, y0 + c * h) - f(op, x0 - a * h, y0 - c * h)) / (2 * h)
+            dt = (f(op, x0 + b * h, y0 + e * h) - f(op, x0 - b * h, y0 - e * h)) / (2 * h)
+            assert got[1] == pytest.approx(ds, rel=1e-6, abs=1e-8)
+            assert got[2] == pytest.approx(dt, rel=1e-6, abs=1e-8)
+    assert list(orc.der2("abs", (-2.0, 3.0, -4.0))) == [2.0, -3.0, 4.0]
+
+
+def test_der2_order_is_lexicographic_and_min_max_follow_the_value():
+    assert orc.der2_partial_cmp((1.0, 5.0, 5.0), (2.0, 0.0, 0.0)) == -1
+    assert orc.der2_partial_cmp((1.0, 0.0, 1.0), (1.0, 0.0, 0.0)) == 1      # equal values: derivatives decide
+    assert orc.der2_partial_cmp((1.0, 2.0, 3.0), (1.0, 2.0, 3.0)) == 0
+    assert orc.der2_partial_cmp((np.nan, 0.0, 0.0), (1.0, 0.0, 0.0)) is None
+    assert orc.der2_partial_cmp((1.0, np.nan, 0.0), (1.0, 0.0, 0.0)) is None
+    assert orc.der2_partial_cmp((1.0, np.nan, 0.0), (2.0, 0.0, 0.0)) == -1  # decided before the NaN is reached
+    # maximum / minimum (src/math/scalar.rs:301-322) compare values only; on a tie maximum takes the right operand
+    assert list(orc.der2("maximum", (1.0, 7.0, 7.0), (1.0, 8.0, 8.0))) == [1.0, 8.0, 8.0]
+    assert list(orc.der2("minimum", (1.0, 7.0, 7.0), (1.0, 8.0, 8.0))) == [1.0, 7.0, 7.0]
+    assert np.isnan(orc.der2("maximum", (np.nan, 1.0, 1.0), (1.0, 0.0, 0.0))[0])
+
+
+def test_kd_tree_simple_matches_the_reference_test():
+    kd = orc.OracleKd([[1.0, 0.0, 0.0], [2.0, 0.0, 0.0], [3.0, 0.0, 0.0]])
+    q = [[0.0, 0.0, 0.0]]
+    idx, dist = kd.nearest(q, 0)
+    assert idx.shape == (1, 0)
+    for k in (1, 2, 3):
+        idx, dist = kd.nearest(q, k)
+        assert list(idx[0]) == [0, 1, 2][:k]
+        assert list(dist[0]) == [1.0, 2.0, 3.0][:k]
+    idx, dist = kd.nearest(q, 5)                                            # more than there are
+    assert list(idx[0]) == [0, 1, 2, rtg.RTG_NONE, rtg.RTG_NONE] and np.isinf(dist[0, 3:]).all()
+
+
+def test_kd_tree_random_matches_brute_force():
+    """src/tree/kd_tree.rs:241-268: 20 seeds, 100 points on an integer lattice, k = 1..9."""
+    for seed in range(1, 21):
+        rng = np.random.default_rng(seed)
+        pts = np.round(rng.random((100, 3)) * 1000.0)
+        kd = orc.OracleKd(pts)
+        assert kd.check()
+        for k in range(1, 10):
+            q = np.round(rng.random((1, 3)) * 1000.0)
+            idx, dist = kd.nearest(q, k)
+            bidx, bdist = kd.nearest_brute(q, k)
+            assert np.array_equal(dist, bdist)
+            if np.unique(bdist).size == k and k < 100:
+                assert np.array_equal(idx, bidx)
+            # the distances reported belong to the entries reported
+            assert np.array_equal(np.sqrt(((pts[idx[0]] - q[0]) ** 2).sum(axis=1)), dist[0]) or \
+                np.allclose(np.linalg.norm(pts[idx[0]] - q[0], axis=1), dist[0], rtol=1e-15)
+
+
+def test_kd_tree_large_and_degenerate_inputs():
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(20000, 3))
+    pts[100:200] = pts[100]                                  # a hundred coincident entries
+    pts[:, 2] = np.where(rng.random(20000) < 0.3, 0.25, pts[:, 2])   # a crowded plane
+    kd = orc.OracleKd(pts)
+    assert kd.check()
+    q = rng.normal(size=(500, 3))
+    for k in (1, 3, 16):
+        _, dist = kd.nearest(q, k)
+        _, bdist = kd.nearest_brute(q, k)
+        assert np.array_equal(dist, bdist)
+    empty = orc.OracleKd(np.zeros((0, 3)))
+    idx, dist = empty.nearest(q[:2], 3)
+    assert (idx == rtg.RTG_NONE).all() and np.isinf(dist).all()
+
+
+def _default_pair():
+    objs, lights, view = scenes.default_objects(0)
+    return scenes.Pair(None, objs, {}), np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
+
+
+def test_photon_pass_keeps_paths_behind_a_specular_bounce():
+    pair, lights = _default_pair()
+    dirs = np.stack([orc.fibonacci_zenith_y(4000, seed=l + 1) for l in range(lights.shape[0])])
+    photons = pair.cpu.photons_emit(lights, dirs)
+    assert photons.shape[0] > 0
+    assert (photons["n_bounces"] >= 1).all() and (photons["n_bounces"] <= 3).all()
+    # the glass sphere (object 0) is the only specular surface of the default scene
+    for i in range(3):
+        used = photons["n_bounces"] > i
+        assert (photons["surface_object"][used, i] == 0).all()
+        assert (photons["surface_object"][~used, i] == rtg.RTG_NONE).all()
+    assert (photons["surface_leaf"] == rtg.RTG_NONE).all()
+    # the same paths come out of the unfiltered path tree of the photon's ray
+    k = 0
+    for l in range(lights.shape[0]):
+        rays = np.concatenate([np.broadcast_to(lights["position"][l], (dirs.shape[1], 3)),
+                               np.array([orc.zenith_y_into_normal(dd) for dd in dirs[l]])], axis=1)
+        paths = pair.cpu.trace_paths(rays)
+        deep = paths[paths["depth"] >= 1]
+        got = photons[k:k + deep.shape[0]]
+        assert (got["light_index"] == l).all()
+        assert np.array_equal(got["position"], deep["point"]["position"])
+        assert np.array_equal(got["modes"], deep["modes"]) and np.array_equal(got["n_bounces"], deep["depth"])
+        assert np.array_equal(got["light"], lights["color"][l][None, :] * deep["attenuation"][:, None])
+        assert np.array_equal(got["dir"], dirs[l][deep["ray"]])
+        k += deep.shape[0]
+    assert k == photons.shape[0]
+
+
+def _floor_point(pair, position):
+    """The RaycastPoint of the checker floor straight below `position` (what a camera path would hand over)."""
+    ray = np.array([[position[0], 0.5, position[2], 0.0, -1.0, 0.0]])
+    # from above the sphere the ray may hit glass first: start just above the floor instead
+    ray[0, 1] = -0.45
+    _, pts, _ = pair.cpu.trace(ray, points=True)
+    assert pts[0]["manifold_len"] == 1 and pts[0]["manifold"][0] == 1
+    return pts[0]
+
+
+def test_newton_correction_lands_the_photon_on_the_point():
+    pair, lights = _default_pair()
+    dirs = np.stack([orc.fibonacci_zenith_y(20000, seed=9)])
+    photons = pair.cpu.photons_emit(lights[:1], dirs)
+    on_floor = photons[(photons["n_bounces"] == 2) & (photons["modes"] == 3) & (np.abs(photons["position"][:, 1] + 0.5) < 1e-9)]
+    assert on_floor.shape[0] > 10                          # refracted in and out of the glass, landed on the floor
+    rng = np.random.default_rng(1)
+    checked = 0
+    for ph in on_floor[:40]:
+        target = ph["position"] + np.array([rng.uniform(-2e-3, 2e-3), 0.0, rng.uniform(-2e-3, 2e-3)])
+        pt = _floor_point(pair, target)
+        r = pair.cpu.photon_adjust(ph, pt, newton_steps=5)
+        if not r["landed"]:
+            continue
+        seps = np.abs(r["seps"]).max(axis=1)
+        assert seps[0] < 5e-3 and seps[-1] < 1e-9 * max(1.0, seps[0] / 1e-6)      # quadratic convergence
+        assert np.linalg.norm(r["position"] - pt["position"]) < 1e-8
+        # the derivative slots are d(position)/d(zenith), d(position)/d(y): compare with re-traced neighbours
+        h = 1e-6
+        for slot, key in ((0, "d0"), (1, "d1")):
+            moved = []
+            for s in (+h, -h):
+                q = ph.copy()
+                dd = r["dir"].copy()
+                dd[slot] += s
+                q["dir"] = dd
+                moved.append(pair.cpu.photon_adjust(q, pt, newton_steps=0)["position"])
+            fd = (moved[0] - moved[1]) / (2 * h)
+            assert np.allclose(r[key], fd, rtol=1e-4, atol=1e-6)
+        checked += 1
+    assert checked >= 10
+
+
+def test_indirect_irradiance_of_the_caustic():
+    pair, lights = _default_pair()
+    dirs = np.stack([orc.fibonacci_zenith_y(30000, seed=l + 3) for l in range(lights.shape[0])])
+    photons = pair.cpu.photons_emit(lights, dirs)
+    kd = orc.OracleKd(photons["position"])
+    on_floor = photons[np.abs(photons["position"][:, 1] + 0.5) < 1e-9]
+    pts = np.array([_floor_point(pair, p) for p in on_floor["position"][:60]])
+    rgb = pair.cpu.indirect_irrad(kd, photons, pts, photon_samples=3, newton_steps=5, newton_epsilon=1e-5)
+    assert np.isfinite(rgb).all() and (rgb >= 0).all()
+    assert (rgb.sum(axis=1) > 0).mean() > 0.8            # a point where a photon landed is lit through the glass
+    assert (rgb[:, 0] == 0).all()                        # the lights are blue and green
+    # one light, one sample: the value is light / (4 pi |dP/da x dP/db|) of the corrected photon
+    one = pair.cpu.indirect_irrad(kd, photons, pts[:10], photon_samples=1, newton_steps=5, newton_epsilon=1e-5)
+    idx, _ = kd.nearest(pts[:10]["position"], 1)
+    for i in range(10):
+        ph = photons[idx[i, 0]]
+        r = pair.cpu.photon_adjust(ph, pts[i], newton_steps=5)
+        if r["landed"] and np.linalg.norm(r["position"] - pts[i]["position"]) < 1e-5:
+            area = 4.0 * np.pi * np.linalg.norm(np.cross(r["d0"], r["d1"]))
+            assert np.allclose(one[i], ph["light"] / area, rtol=1e-12, atol=0)
+        else:
+            assert (one[i] == 0).all()
+    # a point far from every photon path gets nothing: the corrected photon cannot land within epsilon
+    far = _floor_point(pair, np.array([30.0, -0.5, -40.0]))
+    assert (pair.cpu.indirect_irrad(kd, photons, np.array([far]), 3, 5, 1e-5) == 0).all()
+    # and a miss (manifold_len 0) is black
+    miss = np.zeros(1, dtype=rtg.POINT_DTYPE)
+    assert (pair.cpu.indirect_irrad(kd, photons, miss, 3, 5, 1e-5) == 0).all()
