@@ -413,6 +413,15 @@ int rtg_photon_map_nearest(rtg_photon_map *map, const double *queries3, uint64_t
 int rtg_indirect_irrad(rtg_scene *scene, rtg_photon_map *map, const rtg_point *points, uint64_t n_points,
                        uint32_t photon_samples, uint32_t newton_steps, double newton_epsilon, double *rgb_out);
 
+/* `raytrace_pixel` (src/render/renderer.rs:266-283) with the photon term: per pixel of the tile, the sum over the
+ * camera ray's specular paths of (indirect + direct + ambient) x diffuse x attenuation -- rtg_render_frame plus
+ * rtg_indirect_irrad at every path's hit point.  max_depth 1..4 (the reference's constant is 4).  Pixels whose paths
+ * receive no photon are bit-identical to rtg_render_frame's.  Any one of out_rgb / out_rgba8 may be NULL. */
+int rtg_render_frame_photons(rtg_scene *scene, const rtg_view *view, const rtg_light *lights, uint32_t n_lights,
+                             rtg_photon_map *map, uint32_t photon_samples, uint32_t newton_steps, double newton_epsilon,
+                             uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth, double *out_rgb,
+                             uint8_t *out_rgba8);
+
 /* ---- several GPUs ----------------------------------------------------- */
 
 /* The path has no exchange during compute: the scene is replicated and pixels / frames are independent

@@ -1707,4 +1707,37 @@ void orc_photon_adjust(const orc_scene *s, const rtg_photon *ph, const rtg_point
     }
 }
 
+// raytrace_pixel (render/renderer.rs:266-283) with the photon map in place, per pixel of the tile
+int orc_render_frame_photons(const orc_scene *s, const rtg_view *view, const rtg_light *lights, uint32_t n_lights,
+                             const orc_kd *kd, const rtg_photon *photons, uint32_t photon_samples, uint32_t newton_steps,
+                             double newton_epsilon, uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth,
+                             double *out_rgb, uint8_t *out_rgba8, int threads) {
+    uint64_t n = (uint64_t)tile.w * tile.h;
+    parallel_for(n, threads, [&](uint64_t i) {
+        uint32_t x = tile.x0 + (uint32_t)(i % tile.w), y = tile.y0 + (uint32_t)(i / tile.w);
+        double sxy[2];
+        pixel_ndc(x, y, width, height, sxy);
+        Ray ray = view_get_ray(*view, sxy);
+        Counters c;
+        std::vector<PathPoint> paths;
+        all_specular_rec(*s, ray, 1.0, 0, max_depth, paths, c);
+        V3 total = mk(0.0, 0.0, 0.0);
+        for (const PathPoint &pp : paths) {
+            rtg_point pt;
+            point_to_c(true, pp.point, nullptr, &pt);
+            V3 indirect = gen::compute_indirect_irrad(*s, kd->tree, photons, pt, photon_samples, newton_steps, newton_epsilon, 4);
+            V3 irrad = (indirect + compute_direct_irrad(*s, lights, n_lights, pp.point.position, pp.point.inter_normal, c)) +
+                       mk(0.0, 0.0, 0.0);
+            total = total + map_mul(irrad, pp.point.material.diffuse) * pp.attenuation;
+        }
+        if (out_rgb)
+            for (int k = 0; k < 3; k++) out_rgb[i * 3 + k] = total[k];
+        if (out_rgba8) {
+            for (int k = 0; k < 3; k++) out_rgba8[i * 4 + k] = pq8(total[k]);
+            out_rgba8[i * 4 + 3] = 255;
+        }
+    });
+    return 0;
+}
+
 } // extern "C"

@@ -142,6 +142,10 @@ int orc_photons_emit(const orc_scene *s, const rtg_light *lights, uint32_t n_lig
 int orc_indirect_irrad(const orc_scene *s, const orc_kd *kd, const rtg_photon *photons, const rtg_point *points,
                        uint64_t n_points, uint32_t photon_samples, uint32_t newton_steps, double newton_epsilon,
                        uint32_t max_depth, double *rgb_out, int threads);
+int orc_render_frame_photons(const orc_scene *s, const rtg_view *view, const rtg_light *lights, uint32_t n_lights,
+                             const orc_kd *kd, const rtg_photon *photons, uint32_t photon_samples, uint32_t newton_steps,
+                             double newton_epsilon, uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth,
+                             double *out_rgb, uint8_t *out_rgba8, int threads);
 void orc_photon_adjust(const orc_scene *s, const rtg_photon *ph, const rtg_point *p, uint32_t newton_steps, uint32_t max_depth,
                        double *out12, double *out_seps);
 

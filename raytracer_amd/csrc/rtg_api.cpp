@@ -1318,7 +1318,8 @@ namespace {
 // occluder table (*ray_hits) -- then one resolve pass.
 int shade_wavefront(rtg_ctx *ctx, const DevScene &ds, const rtg_light *d_lights, uint32_t n_lights,
                     const rtg_point *d_points, uint64_t n_points, double *d_rgb, uint8_t *d_rgba8,
-                    const double *d_rays = nullptr, uint64_t n_rays = 0, const rtg_hit **ray_hits = nullptr) {
+                    const double *d_rays = nullptr, uint64_t n_rays = 0, const rtg_hit **ray_hits = nullptr,
+                    const double *d_indirect = nullptr) {
     int rc;
     void *occ = nullptr;
     const uint64_t n_shadow = (uint64_t)n_lights * n_points;
@@ -1333,7 +1334,7 @@ int shade_wavefront(rtg_ctx *ctx, const DevScene &ds, const rtg_light *d_lights,
     }
     if (ray_hits) *ray_hits = (const rtg_hit *)occ + n_shadow;
     HIP_TRY(ctx, launch_shade_resolve(ctx->stream, ds, d_lights, n_lights, d_points, n_points, (const rtg_hit *)occ,
-                                      d_rgb, d_rgba8));
+                                      d_rgb, d_rgba8, d_indirect));
     return RTG_OK;
 }
 
@@ -1435,6 +1436,25 @@ int frame_wavefront(rtg_ctx *ctx, const DevScene &ds, const rtg_view &view, uint
     return RTG_OK;
 }
 } // namespace
+
+extern "C++" {
+namespace rtg {
+int api_shade_points(rtg_scene *scene, const rtg_light *d_lights, uint32_t n_lights, const rtg_point *d_points, uint64_t n,
+                     const double *d_indirect, double *d_rgb) {
+    rtg_ctx *ctx = scene->ctx;
+    if (n == 0) return RTG_OK;
+    if (n > 0xFFFFFFFFull || (n_lights != 0 && n > 0xFFFFFFFFull / n_lights))
+        return fail(ctx, RTG_E_LIMIT, "too many points for one shading launch");
+    int rc;
+    DevScene ds;
+    if ((rc = scene_for_launch(scene, (n + kBlock - 1) / kBlock * kBlock, ds)) != RTG_OK) return rc;
+    if (ctx->traversal == 2 && scene->has_mesh)
+        return shade_wavefront(ctx, ds, d_lights, n_lights, d_points, n, d_rgb, nullptr, nullptr, 0, nullptr, d_indirect);
+    HIP_TRY(ctx, launch_shade_direct(ctx->stream, ds, d_lights, n_lights, d_points, n, d_rgb, nullptr, d_indirect));
+    return RTG_OK;
+}
+} // namespace rtg
+} // extern "C++"
 
 int rtg_shade_direct(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const rtg_point *points,
                      uint64_t n_points, double *rgb_out, uint8_t *rgba8_out) {

@@ -73,4 +73,8 @@ int api_bind_scene(rtg_scene *scene);
 // Closest hits of `n` device-resident rays into device memory, through the context's traversal (what rtg_trace
 // does between its input and output staging); asynchronous on the context's stream.
 int api_trace_device(rtg_scene *scene, const double *d_rays6, uint64_t n, rtg_hit *d_hits);
+// (indirect + direct + ambient) x diffuse for device-resident points (what rtg_shade_direct computes, with the photon
+// map's term `d_indirect`, 3 doubles per point or null, added first); asynchronous on the context's stream.
+int api_shade_points(rtg_scene *scene, const rtg_light *d_lights, uint32_t n_lights, const rtg_point *d_points, uint64_t n,
+                     const double *d_indirect, double *d_rgb);
 } // namespace rtg

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(kBlock) void k_points_batch(DevScene s, const doubl
 template <bool PATCH>
 __global__ __launch_bounds__(kBlock) void k_shade_direct(DevScene s, const rtg_light *__restrict__ lights,
                                                           uint32_t n_lights, const rtg_point *__restrict__ points,
-                                                          uint64_t n, double *rgb_out, uint8_t *rgba8_out) {
+                                                          uint64_t n, const double *__restrict__ indirect,
+                                                          double *rgb_out, uint8_t *rgba8_out) {
     __shared__ uint32_t lds[kLdsLevels * kBlock];
     uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= n) return;
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(kBlock) void k_shade_direct(DevScene s, const rtg_l
     V3 total = mk(0.0, 0.0, 0.0);
     if (pt.manifold_len != 0) {
         Counter ctr;
-        V3 irrad = (mk(0.0, 0.0, 0.0) + direct_irrad<false, PATCH>(s, lights, n_lights, ld3(pt.position),
-                                                             ld3(pt.inter_normal), tc, ctr)) +
+        // indirect + direct + ambient (renderer.rs:270-273); without a photon map the indirect term is Color::default()
+        V3 irrad = ((indirect ? ld3(indirect + gid * 3) : mk(0.0, 0.0, 0.0)) +
+                    direct_irrad<false, PATCH>(s, lights, n_lights, ld3(pt.position), ld3(pt.inter_normal), tc, ctr)) +
                    mk(0.0, 0.0, 0.0);
         const DevMaterial &m = material_of_slot(s, pt.material_slot);
         V3 dm = mk(irrad.x * m.diffuse[0], irrad.y * m.diffuse[1], irrad.z * m.diffuse[2]);
@@ -163,7 +165,8 @@ __global__ __launch_bounds__(kBlock) void k_shade_direct(DevScene s, const rtg_l
 __global__ __launch_bounds__(kBlock) void k_shade_resolve(DevScene s, const rtg_light *__restrict__ lights,
                                                            uint32_t n_lights, const rtg_point *__restrict__ points,
                                                            uint64_t n, const rtg_hit *__restrict__ occluders,
-                                                           double *rgb_out, uint8_t *rgba8_out) {
+                                                           const double *__restrict__ indirect, double *rgb_out,
+                                                           uint8_t *rgba8_out) {
     uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= n) return;
     const rtg_point &pt = points[gid];
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_resolve(DevScene s, const rtg_
             double occ_t = __longlong_as_double((long long)(((uint64_t)o.w << 32) | o.z));
             lighting = add_light(lighting, lights[i], q, o.x != RTG_NONE, occ_t);
         }
-        V3 irrad = (mk(0.0, 0.0, 0.0) + lighting) + mk(0.0, 0.0, 0.0);
+        V3 irrad = ((indirect ? ld3(indirect + gid * 3) : mk(0.0, 0.0, 0.0)) + lighting) + mk(0.0, 0.0, 0.0);
         const DevMaterial &m = material_of_slot(s, pt.material_slot);
         V3 dm = mk(irrad.x * m.diffuse[0], irrad.y * m.diffuse[1], irrad.z * m.diffuse[2]);
         total = total + dm * 1.0;
@@ -358,13 +361,14 @@ hipError_t launch_trace(hipStream_t stream, const DevScene &s, const double *ray
 }
 
 hipError_t launch_shade_direct(hipStream_t stream, const DevScene &s, const rtg_light *lights, uint32_t n_lights,
-                               const rtg_point *points, uint64_t n, double *rgb_out, uint8_t *rgba8_out) {
+                               const rtg_point *points, uint64_t n, double *rgb_out, uint8_t *rgba8_out,
+                               const double *indirect) {
     if (n == 0) return hipSuccess;
     dim3 grid((uint32_t)((n + kBlock - 1) / kBlock)), block(kBlock);
     if (s.has_patches)
-        hipLaunchKernelGGL(k_shade_direct<true>, grid, block, 0, stream, s, lights, n_lights, points, n, rgb_out, rgba8_out);
+        hipLaunchKernelGGL(k_shade_direct<true>, grid, block, 0, stream, s, lights, n_lights, points, n, indirect, rgb_out, rgba8_out);
     else
-        hipLaunchKernelGGL(k_shade_direct<false>, grid, block, 0, stream, s, lights, n_lights, points, n, rgb_out, rgba8_out);
+        hipLaunchKernelGGL(k_shade_direct<false>, grid, block, 0, stream, s, lights, n_lights, points, n, indirect, rgb_out, rgba8_out);
     return hipGetLastError();
 }
 
@@ -393,10 +397,10 @@ hipError_t launch_points_batch(hipStream_t stream, const DevScene &s, const doub
 
 hipError_t launch_shade_resolve(hipStream_t stream, const DevScene &s, const rtg_light *lights, uint32_t n_lights,
                                 const rtg_point *points, uint64_t n, const rtg_hit *occluders, double *rgb_out,
-                                uint8_t *rgba8_out) {
+                                uint8_t *rgba8_out, const double *indirect) {
     if (n == 0) return hipSuccess;
     dim3 grid((uint32_t)((n + kBlock - 1) / kBlock)), block(kBlock);
-    hipLaunchKernelGGL(k_shade_resolve, grid, block, 0, stream, s, lights, n_lights, points, n, occluders, rgb_out,
+    hipLaunchKernelGGL(k_shade_resolve, grid, block, 0, stream, s, lights, n_lights, points, n, occluders, indirect, rgb_out,
                        rgba8_out);
     return hipGetLastError();
 }

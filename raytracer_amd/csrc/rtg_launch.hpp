@@ -13,8 +13,10 @@ hipError_t launch_render_primary(hipStream_t stream, const DevScene &s, const rt
                                  rtg_ray_counters *out_counters);
 hipError_t launch_trace(hipStream_t stream, const DevScene &s, const double *rays6, uint64_t n, rtg_hit *out_hits,
                         rtg_point *out_points, rtg_ray_counters *out_counters);
+// `indirect` (3 doubles per point, or null) is the photon map's term of the irradiance sum.
 hipError_t launch_shade_direct(hipStream_t stream, const DevScene &s, const rtg_light *lights, uint32_t n_lights,
-                               const rtg_point *points, uint64_t n, double *rgb_out, uint8_t *rgba8_out);
+                               const rtg_point *points, uint64_t n, double *rgb_out, uint8_t *rgba8_out,
+                               const double *indirect = nullptr);
 hipError_t launch_render_frame(hipStream_t stream, const DevScene &s, const rtg_view &view, const rtg_light *lights,
                                uint32_t n_lights, uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth,
                                double *out_rgb, uint8_t *out_rgba8, rtg_hit *out_hits,
@@ -59,7 +61,7 @@ hipError_t launch_shadow_phased(hipStream_t stream, const DevScene &s, const rtg
 // compute_direct_irrad x diffuse from occluders found by launch_shadow_phased.
 hipError_t launch_shade_resolve(hipStream_t stream, const DevScene &s, const rtg_light *lights, uint32_t n_lights,
                                 const rtg_point *points, uint64_t n, const rtg_hit *occluders, double *rgb_out,
-                                uint8_t *rgba8_out);
+                                uint8_t *rgba8_out, const double *indirect = nullptr);
 
 // Specular path tree as levels of ray batches (rtg_specular.hip).
 struct SpecMeta {
@@ -152,6 +154,12 @@ hipError_t launch_photon_final_bounce(hipStream_t stream, const PhotonPairs &p, 
                                       double *rays6, uint32_t *status, double *landing);
 hipError_t launch_photon_sum(hipStream_t stream, const PhotonPairs &p, const uint32_t *status, const double *landing,
                              double newton_epsilon, double *rgb);
+
+// A frame from path records: camera rays of a tile, and the per-pixel sum of path_rgb[j] * attenuation over a
+// pixel's paths (pixels without paths are black), optionally PQ-encoded to 8 bits.
+hipError_t launch_camera_rays(hipStream_t stream, const rtg_view &view, uint32_t width, uint32_t height, rtg_rect tile, double *rays6);
+hipError_t launch_frame_from_paths(hipStream_t stream, const rtg_path *paths, uint32_t n_paths, const double *path_rgb,
+                                   uint64_t n_pixels, double *out_rgb, uint8_t *out_rgba8);
 
 // Looks up this GPU's copy of the fixed scratch array behind rtg_render_primary_static (rtg_static.hip); called
 // with `device` current, once per device (later calls return at once).

@@ -698,6 +698,45 @@ __global__ __launch_bounds__(256) void k_indirect_sum(Pairs pr, const uint32_t *
     rgb[i * 3 + 2] = total.z;
 }
 
+// ---- a frame with the photon term ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_camera_rays(rtg_view view, uint32_t width, uint32_t height, rtg_rect tile,
+                                                     double *__restrict__ rays6) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)tile.w * tile.h) return;
+    const uint32_t py = (uint32_t)(i / tile.w), px = (uint32_t)(i - (uint64_t)py * tile.w);
+    const Ray r = primary_ray(view, tile.x0 + px, tile.y0 + py, width, height);
+    double *w = rays6 + i * 6;
+    w[0] = r.o.x;
+    w[1] = r.o.y;
+    w[2] = r.o.z;
+    w[3] = r.d.x;
+    w[4] = r.d.y;
+    w[5] = r.d.z;
+}
+// raytrace_pixel's sum (render/renderer.rs:268-278): a pixel's paths are adjacent records, in the order the
+// recursion emitted them, the first of them at depth 0; path_rgb[j] = irrad.map_mul(diffuse) of path j.
+__global__ __launch_bounds__(256) void k_frame_sum_paths(const rtg_path *__restrict__ paths, uint32_t n_paths,
+                                                         const double *__restrict__ path_rgb, double *__restrict__ out_rgb) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_paths || paths[i].depth != 0) return;
+    const uint32_t ray = paths[i].ray;
+    V3 total = mk(0.0, 0.0, 0.0);
+    for (uint32_t j = i; j < n_paths && paths[j].ray == ray; j++) total = total + ld3(path_rgb + (size_t)j * 3) * paths[j].attenuation;
+    out_rgb[(size_t)ray * 3] = total.x;
+    out_rgb[(size_t)ray * 3 + 1] = total.y;
+    out_rgb[(size_t)ray * 3 + 2] = total.z;
+}
+__global__ __launch_bounds__(256) void k_frame_pq8(const double *__restrict__ rgb, uint64_t n, uint8_t *__restrict__ rgba8) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uchar4 c;
+    c.x = pq8(rgb[i * 3]);
+    c.y = pq8(rgb[i * 3 + 1]);
+    c.z = pq8(rgb[i * 3 + 2]);
+    c.w = 255;
+    reinterpret_cast<uchar4 *>(rgba8)[i] = c;
+}
+
 template <int K>
 void launch_kd(hipStream_t stream, const void *nodes, uint32_t n, const double *q, uint64_t nq, uint32_t k, uint32_t *oi, double *od) {
     hipLaunchKernelGGL(k_kd_nearest<K>, dim3((uint32_t)((nq + 127) / 128)), dim3(128), 0, stream, (const KdNode *)nodes, n, q, nq, k, oi, od);
@@ -738,6 +777,24 @@ hipError_t launch_photons_from_paths(hipStream_t stream, const rtg_path *paths, 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_photon_write, dim3(blocks), dim3(256), 0, stream, paths, n_paths, offsets, dirs2, lights, first_ray,
                        count_per_light, room, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_camera_rays(hipStream_t stream, const rtg_view &view, uint32_t width, uint32_t height, rtg_rect tile, double *rays6) {
+    const uint64_t n = (uint64_t)tile.w * tile.h;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_camera_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, view, width, height, tile, rays6);
+    return hipGetLastError();
+}
+hipError_t launch_frame_from_paths(hipStream_t stream, const rtg_path *paths, uint32_t n_paths, const double *path_rgb,
+                                   uint64_t n_pixels, double *out_rgb, uint8_t *out_rgba8) {
+    if (n_pixels == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(out_rgb, 0, (size_t)n_pixels * 3 * sizeof(double), stream);   // a pixel without paths is black
+    if (e != hipSuccess) return e;
+    if (n_paths)
+        hipLaunchKernelGGL(k_frame_sum_paths, dim3((n_paths + 255) / 256), dim3(256), 0, stream, paths, n_paths, path_rgb, out_rgb);
+    if (out_rgba8)
+        hipLaunchKernelGGL(k_frame_pq8, dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, stream, out_rgb, n_pixels, out_rgba8);
     return hipGetLastError();
 }
 

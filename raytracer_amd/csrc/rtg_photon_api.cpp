@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <limits>
 #include <new>
 #include <thread>
@@ -132,6 +133,70 @@ int copy_out(rtg_ctx *ctx, void *user, const void *dev, size_t bytes) {
     if (bytes == 0) return RTG_OK;
     HIP_TRY(ctx, hipMemcpyAsync(user, dev, bytes, api_is_device_pointer(user) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                                 ctx->stream));
+    return RTG_OK;
+}
+
+int check_irrad_args(rtg_scene *scene, rtg_photon_map *map, uint32_t photon_samples) {
+    rtg_ctx *ctx = scene->ctx;
+    if (!map) return api_fail(ctx, RTG_E_INVALID, "photon map is null");
+    if (map->device != scene->device) return api_fail(ctx, RTG_E_INVALID, "the photon map lives on another GPU");
+    if (photon_samples > 16) return api_fail(ctx, RTG_E_LIMIT, "photon_samples is at most 16");
+    if (scene->dev.has_patches) return api_fail(ctx, RTG_E_UNSUPPORTED, "the photon term does not support scenes with patch sets");
+    return RTG_OK;
+}
+
+// compute_indirect_irrad for device-resident points into device memory (3 doubles per point); asynchronous on the
+// scene's stream.
+int indirect_device(rtg_scene *scene, rtg_photon_map *map, const rtg_point *d_points, uint64_t n_points, uint32_t photon_samples,
+                    uint32_t newton_steps, double newton_epsilon, double *d_rgb) {
+    rtg_ctx *ctx = scene->ctx;
+    int rc;
+    if (n_points == 0) return RTG_OK;
+    const uint64_t n_pairs = n_points * photon_samples;
+    if (n_pairs > 0xFFFFFFFFull) return api_fail(ctx, RTG_E_LIMIT, "more than 2^32-1 (point, photon sample) pairs in one call");
+    if (photon_samples == 0 || map->n == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(d_rgb, 0, (size_t)n_points * 3 * sizeof(double), ctx->stream));
+        return RTG_OK;
+    }
+    void *queries = nullptr, *nearest = nullptr, *dist = nullptr, *dir2 = nullptr, *state = nullptr, *rays = nullptr, *hits = nullptr,
+         *status = nullptr, *landing = nullptr, *leaves = nullptr;
+    if ((rc = api_scratch(ctx, "irrad_queries", (size_t)n_points * 3 * sizeof(double), &queries)) != RTG_OK) return rc;
+    if ((rc = api_scratch(ctx, "irrad_nearest", (size_t)n_pairs * sizeof(uint32_t), &nearest)) != RTG_OK) return rc;
+    if ((rc = api_scratch(ctx, "irrad_distance", (size_t)n_pairs * sizeof(double), &dist)) != RTG_OK) return rc;
+    if ((rc = api_scratch(ctx, "irrad_dir", (size_t)n_pairs * 2 * sizeof(double), &dir2)) != RTG_OK) return rc;
+    if ((rc = api_scratch(ctx, "irrad_state", (size_t)n_pairs * 18 * sizeof(double), &state)) != RTG_OK) return rc;
+    if ((rc = api_scratch(ctx, "irrad_rays", (size_t)n_pairs * 6 * sizeof(double), &rays)) != RTG_OK) return rc;
+    if ((rc = api_scratch(ctx, "irrad_hits", (size_t)n_pairs * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
+    if ((rc = api_scratch(ctx, "irrad_status", (size_t)n_pairs * sizeof(uint32_t), &status)) != RTG_OK) return rc;
+    if ((rc = api_scratch(ctx, "irrad_landing", (size_t)n_pairs * 9 * sizeof(double), &landing)) != RTG_OK) return rc;
+    if ((rc = api_scratch(ctx, "irrad_leaves", std::max<size_t>(1, scene->object_leaves.size()) * sizeof(uint64_t), &leaves)) != RTG_OK)
+        return rc;
+    if (!scene->object_leaves.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(leaves, scene->object_leaves.data(), scene->object_leaves.size() * sizeof(uint64_t),
+                                    hipMemcpyHostToDevice, ctx->stream));
+    // the points' positions are the queries: a strided copy out of the point records
+    HIP_TRY(ctx, hipMemcpy2DAsync(queries, 3 * sizeof(double), (const char *)d_points + offsetof(rtg_point, position),
+                                  sizeof(rtg_point), 3 * sizeof(double), (size_t)n_points, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_kd_nearest(ctx->stream, map->d_nodes, (uint32_t)map->n, (const double *)queries, n_points, photon_samples,
+                                   (uint32_t *)nearest, (double *)dist));
+    PhotonPairs pr;
+    pr.objects = scene->dev.objects;
+    pr.n_objects = scene->dev.n_objects;
+    pr.object_leaves = (const uint64_t *)leaves;
+    pr.photons = (const rtg_photon *)map->d_photons;
+    pr.n_photons = (uint32_t)map->n;
+    pr.nearest = (const uint32_t *)nearest;
+    pr.points = d_points;
+    pr.n_points = n_points;
+    pr.samples = photon_samples;
+    HIP_TRY(ctx, launch_photon_newton(ctx->stream, pr, newton_steps, (double *)dir2));
+    HIP_TRY(ctx, launch_photon_final_start(ctx->stream, pr, (const double *)dir2, (double *)state, (double *)rays, (uint32_t *)status));
+    for (uint32_t level = 0; level <= map->max_bounces; level++) {   // a photon lands after its last bounce
+        if ((rc = api_trace_device(scene, (const double *)rays, n_pairs, (rtg_hit *)hits)) != RTG_OK) return rc;
+        HIP_TRY(ctx, launch_photon_final_bounce(ctx->stream, pr, level, (const rtg_hit *)hits, (double *)state, (double *)rays,
+                                                (uint32_t *)status, (double *)landing));
+    }
+    HIP_TRY(ctx, launch_photon_sum(ctx->stream, pr, (const uint32_t *)status, (const double *)landing, newton_epsilon, d_rgb));
     return RTG_OK;
 }
 
@@ -315,67 +380,87 @@ int rtg_indirect_irrad(rtg_scene *scene, rtg_photon_map *map, const rtg_point *p
     int rc = api_bind_scene(scene);
     if (rc != RTG_OK) return rc;
     rtg_ctx *ctx = scene->ctx;
-    if (!map) return api_fail(ctx, RTG_E_INVALID, "rtg_indirect_irrad: map is null");
-    if (map->device != scene->device) return api_fail(ctx, RTG_E_INVALID, "rtg_indirect_irrad: the photon map lives on another GPU");
-    if (photon_samples > 16) return api_fail(ctx, RTG_E_LIMIT, "rtg_indirect_irrad: photon_samples is at most 16");
-    if (scene->dev.has_patches) return api_fail(ctx, RTG_E_UNSUPPORTED, "rtg_indirect_irrad: scenes with patch sets are not supported");
+    if ((rc = check_irrad_args(scene, map, photon_samples)) != RTG_OK) return rc;
     if (n_points == 0) return RTG_OK;
     if (!points || !rgb_out) return api_fail(ctx, RTG_E_INVALID, "rtg_indirect_irrad: points / rgb_out is null");
-    const uint64_t n_pairs = n_points * photon_samples;
-    if (n_pairs > 0xFFFFFFFFull) return api_fail(ctx, RTG_E_LIMIT, "rtg_indirect_irrad: more than 2^32-1 (point, sample) pairs in one call");
-
     const void *d_points = nullptr;
     if ((rc = api_input(ctx, "irrad_points", points, (size_t)n_points * sizeof(rtg_point), &d_points)) != RTG_OK) return rc;
     const bool out_dev = api_is_device_pointer(rgb_out);
     void *d_rgb = rgb_out;
     if (!out_dev && (rc = api_scratch(ctx, "irrad_rgb", (size_t)n_points * 3 * sizeof(double), &d_rgb)) != RTG_OK) return rc;
-    if (photon_samples == 0 || map->n == 0) {
-        HIP_TRY(ctx, hipMemsetAsync(d_rgb, 0, (size_t)n_points * 3 * sizeof(double), ctx->stream));
-    } else {
-        void *queries = nullptr, *nearest = nullptr, *dist = nullptr, *dir2 = nullptr, *state = nullptr, *rays = nullptr, *hits = nullptr,
-             *status = nullptr, *landing = nullptr, *leaves = nullptr;
-        if ((rc = api_scratch(ctx, "irrad_queries", (size_t)n_points * 3 * sizeof(double), &queries)) != RTG_OK) return rc;
-        if ((rc = api_scratch(ctx, "irrad_nearest", (size_t)n_pairs * sizeof(uint32_t), &nearest)) != RTG_OK) return rc;
-        if ((rc = api_scratch(ctx, "irrad_distance", (size_t)n_pairs * sizeof(double), &dist)) != RTG_OK) return rc;
-        if ((rc = api_scratch(ctx, "irrad_dir", (size_t)n_pairs * 2 * sizeof(double), &dir2)) != RTG_OK) return rc;
-        if ((rc = api_scratch(ctx, "irrad_state", (size_t)n_pairs * 18 * sizeof(double), &state)) != RTG_OK) return rc;
-        if ((rc = api_scratch(ctx, "irrad_rays", (size_t)n_pairs * 6 * sizeof(double), &rays)) != RTG_OK) return rc;
-        if ((rc = api_scratch(ctx, "irrad_hits", (size_t)n_pairs * sizeof(rtg_hit), &hits)) != RTG_OK) return rc;
-        if ((rc = api_scratch(ctx, "irrad_status", (size_t)n_pairs * sizeof(uint32_t), &status)) != RTG_OK) return rc;
-        if ((rc = api_scratch(ctx, "irrad_landing", (size_t)n_pairs * 9 * sizeof(double), &landing)) != RTG_OK) return rc;
-        if ((rc = api_scratch(ctx, "irrad_leaves", std::max<size_t>(1, scene->object_leaves.size()) * sizeof(uint64_t), &leaves)) != RTG_OK)
-            return rc;
-        if (!scene->object_leaves.empty())
-            HIP_TRY(ctx, hipMemcpyAsync(leaves, scene->object_leaves.data(), scene->object_leaves.size() * sizeof(uint64_t),
-                                        hipMemcpyHostToDevice, ctx->stream));
-        // the points' positions are the queries: a strided copy out of the point records
-        HIP_TRY(ctx, hipMemcpy2DAsync(queries, 3 * sizeof(double), (const char *)d_points + offsetof(rtg_point, position),
-                                      sizeof(rtg_point), 3 * sizeof(double), (size_t)n_points, hipMemcpyDeviceToDevice, ctx->stream));
-        HIP_TRY(ctx, launch_kd_nearest(ctx->stream, map->d_nodes, (uint32_t)map->n, (const double *)queries, n_points, photon_samples,
-                                       (uint32_t *)nearest, (double *)dist));
-        PhotonPairs pr;
-        pr.objects = scene->dev.objects;
-        pr.n_objects = scene->dev.n_objects;
-        pr.object_leaves = (const uint64_t *)leaves;
-        pr.photons = (const rtg_photon *)map->d_photons;
-        pr.n_photons = (uint32_t)map->n;
-        pr.nearest = (const uint32_t *)nearest;
-        pr.points = (const rtg_point *)d_points;
-        pr.n_points = n_points;
-        pr.samples = photon_samples;
-        HIP_TRY(ctx, launch_photon_newton(ctx->stream, pr, newton_steps, (double *)dir2));
-        HIP_TRY(ctx, launch_photon_final_start(ctx->stream, pr, (const double *)dir2, (double *)state, (double *)rays, (uint32_t *)status));
-        for (uint32_t level = 0; level <= map->max_bounces; level++) {   // a photon lands after its last bounce
-            if ((rc = api_trace_device(scene, (const double *)rays, n_pairs, (rtg_hit *)hits)) != RTG_OK) return rc;
-            HIP_TRY(ctx, launch_photon_final_bounce(ctx->stream, pr, level, (const rtg_hit *)hits, (double *)state, (double *)rays,
-                                                    (uint32_t *)status, (double *)landing));
-        }
-        HIP_TRY(ctx, launch_photon_sum(ctx->stream, pr, (const uint32_t *)status, (const double *)landing, newton_epsilon, (double *)d_rgb));
-    }
+    if ((rc = indirect_device(scene, map, (const rtg_point *)d_points, n_points, photon_samples, newton_steps, newton_epsilon,
+                              (double *)d_rgb)) != RTG_OK)
+        return rc;
     if (!out_dev) {
         HIP_TRY(ctx, hipMemcpyAsync(rgb_out, d_rgb, (size_t)n_points * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return RTG_OK;
+}
+
+int rtg_render_frame_photons(rtg_scene *scene, const rtg_view *view, const rtg_light *lights, uint32_t n_lights,
+                             rtg_photon_map *map, uint32_t photon_samples, uint32_t newton_steps, double newton_epsilon,
+                             uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth, double *out_rgb,
+                             uint8_t *out_rgba8) {
+    int rc = api_bind_scene(scene);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = scene->ctx;
+    if ((rc = check_irrad_args(scene, map, photon_samples)) != RTG_OK) return rc;
+    if (!view) return api_fail(ctx, RTG_E_INVALID, "rtg_render_frame_photons: view is null");
+    if (n_lights && !lights) return api_fail(ctx, RTG_E_INVALID, "rtg_render_frame_photons: lights is null");
+    if (width == 0 || height == 0) return api_fail(ctx, RTG_E_INVALID, "rtg_render_frame_photons: empty image");
+    if ((uint64_t)tile.x0 + tile.w > width || (uint64_t)tile.y0 + tile.h > height)
+        return api_fail(ctx, RTG_E_INVALID, "rtg_render_frame_photons: tile outside the image");
+    if (max_depth < 1 || max_depth > 4) return api_fail(ctx, RTG_E_INVALID, "rtg_render_frame_photons: max_depth must be 1..4");
+    const uint64_t n = (uint64_t)tile.w * tile.h;
+    if (n == 0) return RTG_OK;
+    if (!out_rgb && !out_rgba8) return api_fail(ctx, RTG_E_INVALID, "rtg_render_frame_photons: no output requested");
+    const uint64_t per_ray = (1ull << max_depth) - 1;
+    if (n * per_ray * (uint64_t)std::max(1u, std::max(n_lights, photon_samples)) > 0xFFFFFFFFull)
+        return api_fail(ctx, RTG_E_LIMIT, "rtg_render_frame_photons: tile too large for one call (render it in bands)");
+    if ((out_rgb && api_is_device_pointer(out_rgb) && (uintptr_t)out_rgb % 16 != 0) ||
+        (out_rgba8 && api_is_device_pointer(out_rgba8) && (uintptr_t)out_rgba8 % 4 != 0))
+        return api_fail(ctx, RTG_E_INVALID, "rtg_render_frame_photons: misaligned device output");
+
+    const void *d_lights = nullptr;
+    if ((rc = api_input(ctx, "frame_lights", lights, (size_t)n_lights * sizeof(rtg_light), &d_lights)) != RTG_OK) return rc;
+    void *rays = nullptr, *paths = nullptr, *points = nullptr, *indirect = nullptr, *path_rgb = nullptr, *frame = nullptr, *c8 = nullptr;
+    if ((rc = api_scratch(ctx, "frame_rays", (size_t)n * 6 * sizeof(double), &rays)) != RTG_OK) return rc;
+    if ((rc = api_scratch(ctx, "frame_paths", (size_t)(n * per_ray) * sizeof(rtg_path), &paths)) != RTG_OK) return rc;
+    HIP_TRY(ctx, launch_camera_rays(ctx->stream, *view, width, height, tile, (double *)rays));
+    uint64_t n_paths = 0;
+    if ((rc = rtg_trace_paths(scene, (const double *)rays, n, max_depth, (rtg_path *)paths, n * per_ray, &n_paths)) != RTG_OK) return rc;
+    if (n_paths) {
+        if ((rc = api_scratch(ctx, "frame_path_points", (size_t)n_paths * sizeof(rtg_point), &points)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "frame_indirect", (size_t)n_paths * 3 * sizeof(double), &indirect)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "frame_path_rgb", (size_t)n_paths * 3 * sizeof(double), &path_rgb)) != RTG_OK) return rc;
+        // the paths' RaycastPoints, packed: what the irradiance terms are evaluated at (renderer.rs:270-273)
+        HIP_TRY(ctx, hipMemcpy2DAsync(points, sizeof(rtg_point), (const char *)paths + offsetof(rtg_path, point), sizeof(rtg_path),
+                                      sizeof(rtg_point), (size_t)n_paths, hipMemcpyDeviceToDevice, ctx->stream));
+        if ((rc = indirect_device(scene, map, (const rtg_point *)points, n_paths, photon_samples, newton_steps, newton_epsilon,
+                                  (double *)indirect)) != RTG_OK)
+            return rc;
+        if ((rc = api_shade_points(scene, (const rtg_light *)d_lights, n_lights, (const rtg_point *)points, n_paths,
+                                   (const double *)indirect, (double *)path_rgb)) != RTG_OK)
+            return rc;
+    }
+    const bool rgb_dev = out_rgb && api_is_device_pointer(out_rgb), c8_dev = out_rgba8 && api_is_device_pointer(out_rgba8);
+    frame = rgb_dev ? (void *)out_rgb : nullptr;
+    if (!frame && (rc = api_scratch(ctx, "frame_rgb_out", (size_t)n * 3 * sizeof(double), &frame)) != RTG_OK) return rc;
+    c8 = c8_dev ? (void *)out_rgba8 : nullptr;
+    if (out_rgba8 && !c8 && (rc = api_scratch(ctx, "frame_rgba8_out", (size_t)n * 4, &c8)) != RTG_OK) return rc;
+    HIP_TRY(ctx, launch_frame_from_paths(ctx->stream, (const rtg_path *)paths, (uint32_t)n_paths, (const double *)path_rgb, n,
+                                         (double *)frame, (uint8_t *)c8));
+    bool staged = false;
+    if (out_rgb && !rgb_dev) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_rgb, frame, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        staged = true;
+    }
+    if (out_rgba8 && !c8_dev) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_rgba8, c8, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        staged = true;
+    }
+    if (staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTG_OK;
 }
 

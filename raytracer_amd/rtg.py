@@ -151,6 +151,8 @@ _sig(lib.rtg_photons_emit, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_u
 _sig(lib.rtg_photon_map_create, C.c_int, _vp, _vp, C.c_uint64, C.POINTER(_vp))
 _sig(lib.rtg_photon_map_destroy, None, _vp)
 _sig(lib.rtg_photon_map_nearest, C.c_int, _vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp)
+_sig(lib.rtg_render_frame_photons, C.c_int, _vp, C.POINTER(View), _vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_double,
+     C.c_uint32, C.c_uint32, Rect, C.c_uint32, _vp, _vp)
 _sig(lib.rtg_indirect_irrad, C.c_int, _vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, _vp)
 
 _sig(lib.rtg_comm_unique_id, C.c_int, _vp)
@@ -790,6 +792,18 @@ class Scene:
         self.ctx._check(lib.rtg_indirect_irrad(self._h, photon_map._h, _ptr(points), points.shape[0], photon_samples,
                                                newton_steps, float(newton_epsilon), _ptr(rgb)))
         return rgb
+
+    def render_frame_photons(self, view, lights, photon_map, width, height, tile=None, max_depth=4, photon_samples=3,
+                             newton_steps=5, newton_epsilon=1e-5, rgba8=True):
+        """raytrace_pixel with the photon term: (rgb (n, 3), rgba8 (n, 4) | None) over the tile."""
+        lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+        x0, y0, w, h = tile if tile is not None else (0, 0, width, height)
+        rgb = np.empty((w * h, 3), dtype=np.float64)
+        c8 = np.empty((w * h, 4), dtype=np.uint8) if rgba8 else None
+        self.ctx._check(lib.rtg_render_frame_photons(self._h, C.byref(view), _ptr(lights), lights.shape[0], photon_map._h,
+                                                     photon_samples, newton_steps, float(newton_epsilon), width, height,
+                                                     Rect(x0, y0, w, h), max_depth, _ptr(rgb), _ptr(c8)))
+        return rgb, c8
 
     def indirect_irrad_raw(self, photon_map, points_ptr, n, photon_samples, newton_steps, newton_epsilon, rgb_ptr):
         self.ctx._check(lib.rtg_indirect_irrad(self._h, photon_map._h, _ptr(points_ptr), n, photon_samples, newton_steps,

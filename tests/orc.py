@@ -85,6 +85,8 @@ _sig(lib.orc_kd_nearest, None, _vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp, C.c_i
 _sig(lib.orc_kd_nearest_brute, None, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint32, _vp, _vp, C.c_int)
 _sig(lib.orc_photons_emit, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64))
 _sig(lib.orc_indirect_irrad, C.c_int, _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, _vp, C.c_int)
+_sig(lib.orc_render_frame_photons, C.c_int, _vp, C.POINTER(rtg.View), _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_double,
+     C.c_uint32, C.c_uint32, rtg.Rect, C.c_uint32, _vp, _vp, C.c_int)
 _sig(lib.orc_photon_adjust, None, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp)
 
 THREADS = min(8, os.cpu_count() or 1)
@@ -414,6 +416,18 @@ class OracleScene:
         lib.orc_indirect_irrad(self._h, kd.handle, photons.ctypes.data, points.ctypes.data, points.shape[0], photon_samples,
                                newton_steps, float(newton_epsilon), max_depth, rgb.ctypes.data, threads)
         return rgb
+
+    def render_frame_photons(self, view, lights, kd, photons, width, height, tile=None, max_depth=4, photon_samples=3,
+                             newton_steps=5, newton_epsilon=1e-5, threads=THREADS):
+        lights = np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
+        photons = np.ascontiguousarray(photons, dtype=rtg.PHOTON_DTYPE)
+        x0, y0, w, h = tile if tile is not None else (0, 0, width, height)
+        rgb = np.empty((w * h, 3), dtype=np.float64)
+        c8 = np.empty((w * h, 4), dtype=np.uint8)
+        lib.orc_render_frame_photons(self._h, C.byref(view), lights.ctypes.data, lights.shape[0], kd.handle, photons.ctypes.data,
+                                     photon_samples, newton_steps, float(newton_epsilon), width, height, rtg.Rect(x0, y0, w, h),
+                                     max_depth, rgb.ctypes.data, c8.ctypes.data, threads)
+        return rgb, c8
 
     def photon_adjust(self, photon, point, newton_steps=5, max_depth=4):
         """Newton iteration + final trace of one photon against one point (see orc_photon_adjust)."""

@@ -247,3 +247,40 @@ def test_caustic_term_through_meshes(gpu_ctx):
     pair.gpu.indirect_irrad_raw(pm, d_pts.data_ptr(), pts.shape[0], 3, 5, 1e-5, d_rgb.data_ptr())
     gpu_ctx.synchronize()
     assert np.array_equal(d_rgb.cpu().numpy().reshape(-1, 3), got)
+
+
+def test_frame_with_the_photon_term(gpu_ctx):
+    """raytrace_pixel with photons (src/render/renderer.rs:266-283): pixels that no photon reaches are bit-identical
+    to the photon-less frame and to the oracle; pixels in the caustic agree within IRRAD_RTOL."""
+    for build in ("default", "meshes"):
+        if build == "default":
+            objs, lights, view = scenes.default_objects(0)
+            lights = _lights(lights)
+            pair = scenes.Pair(gpu_ctx, objs, {})
+        else:
+            pair, lights = _glass_mesh_scene(gpu_ctx)
+            view = scenes.default_objects(0)[2]
+        dirs = np.stack([rtg.fibonacci_zenith_y(200_000, seed=l + 41) for l in range(lights.shape[0])])
+        photons = pair.gpu.photons_emit(lights, dirs)
+        pm = rtg.PhotonMap(gpu_ctx, photons)
+        kd = orc.OracleKd(photons["position"])
+        w = h = 80
+        got, got8 = pair.gpu.render_frame_photons(view, lights, pm, w, h)
+        want, want8 = pair.cpu.render_frame_photons(view, lights, kd, photons, w, h)
+        plain, _, _ = pair.gpu.render_frame(view, lights, w, h, hits=False)
+        caustic = (want != plain).any(axis=1)
+        assert caustic.sum() > 100, build
+        # outside the caustic: the plain frame, bit for bit
+        assert not scenes.float_bits_differ(got[~caustic], plain[~caustic]).any()
+        close = np.isclose(got[caustic], want[caustic], rtol=IRRAD_RTOL, atol=1e-300).all(axis=1)
+        assert close.mean() > 0.99, (build, close.mean())
+        assert (np.abs(got8.astype(int) - want8.astype(int)).max(axis=1) <= 1).mean() > 0.995
+        # a tile of the frame is the frame's pixels
+        tile = (17, 9, 40, 33)
+        t_rgb, _ = pair.gpu.render_frame_photons(view, lights, pm, w, h, tile=tile)
+        sub = got.reshape(h, w, 3)[tile[1]:tile[1] + tile[3], tile[0]:tile[0] + tile[2]].reshape(-1, 3)
+        assert not scenes.float_bits_differ(t_rgb, sub).any()
+        # an empty map gives the plain frame
+        empty = rtg.PhotonMap(gpu_ctx, photons[:0])
+        e_rgb, _ = pair.gpu.render_frame_photons(view, lights, empty, w, h)
+        assert not scenes.float_bits_differ(e_rgb, plain).any()
