@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Timings of the photon-map path on the reference's default scene (glass sphere over a checker floor, two lights;
+src/lib.rs:42-121): the photon pass, the k-d tree build, nearest photons, the caustic term and a frame with it.
+Usage: tools/photon_prof.py [photons per light (default 2000000)] [frame side (default 800)]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from raytracer_amd import rtg  # noqa: E402
+
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+side = int(sys.argv[2]) if len(sys.argv) > 2 else 800
+with_oracle = os.environ.get("PHOTON_PROF_ORACLE", "1") != "0"
+
+ctx = rtg.Context(0)
+objs, lights, view = rtg.scene_builder(0)
+lights = np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
+scene = ctx.scene(objs)
+
+
+def timed(label, fn, unit_count=None, unit=""):
+    fn()                                   # warm-up: scratch buffers get their size
+    ctx.synchronize()
+    t = time.perf_counter()
+    out = fn()
+    ctx.synchronize()
+    dt = time.perf_counter() - t
+    rate = f"  {unit_count / dt / 1e6:10.2f} M{unit}/s" if unit_count else ""
+    print(f"{label:42s} {dt * 1e3:10.2f} ms{rate}", flush=True)
+    return out, dt
+
+
+dirs = np.stack([rtg.fibonacci_zenith_y(count, seed=l + 1) for l in range(lights.shape[0])])
+photons, _ = timed(f"photon pass, {lights.shape[0]} x {count} directions", lambda: scene.photons_emit(lights, dirs), lights.shape[0] * count, "rays")
+print(f"  photons kept: {photons.shape[0]}  by bounces {np.bincount(photons['n_bounces']).tolist()}")
+t = time.perf_counter()
+pm = rtg.PhotonMap(ctx, photons)
+print(f"{'k-d tree build (host) + upload':42s} {(time.perf_counter() - t) * 1e3:10.2f} ms")
+
+hits, pts, _ = scene.render_primary(view, side, side, points=True)
+q = np.ascontiguousarray(pts["position"])
+for k in (1, 3, 16):
+    timed(f"nearest photons, {q.shape[0]} queries, k = {k}", lambda: pm.nearest(q, k), q.shape[0], "queries")
+for samples, steps in ((3, 5), (3, 0), (1, 5)):
+    timed(f"caustic term, {pts.shape[0]} points, {samples} samples, {steps} steps", lambda: scene.indirect_irrad(pm, pts, samples, steps, 1e-5),
+          pts.shape[0] * samples, "pairs")
+timed(f"frame {side}x{side} without photons", lambda: scene.render_frame(view, lights, side, side, hits=False), side * side, "pixels")
+timed(f"frame {side}x{side} with the photon term", lambda: scene.render_frame_photons(view, lights, pm, side, side), side * side, "pixels")
+
+if with_oracle:
+    import orc
+    import scenes
+    pair = scenes.Pair(None, objs, {})
+    kd = orc.OracleKd(photons["position"])
+    sub = pts[:: max(1, pts.shape[0] // 100_000)]
+    for threads in (1, orc.THREADS):
+        t = time.perf_counter()
+        kd.nearest(np.ascontiguousarray(sub["position"]), 3, threads=threads)
+        dt = time.perf_counter() - t
+        print(f"oracle nearest photons, {sub.shape[0]} queries, k = 3, {threads} threads: {dt * 1e3:9.1f} ms  {sub.shape[0] / dt / 1e6:8.3f} Mqueries/s")
+        t = time.perf_counter()
+        pair.cpu.indirect_irrad(kd, photons, sub, 3, 5, 1e-5, threads=threads)
+        dt = time.perf_counter() - t
+        print(f"oracle caustic term, {sub.shape[0]} points, 3 samples, 5 steps, {threads} threads: {dt * 1e3:9.1f} ms  {sub.shape[0] * 3 / dt / 1e6:8.3f} Mpairs/s")
