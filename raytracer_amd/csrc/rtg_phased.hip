@@ -60,6 +60,8 @@ enum : uint32_t { PH_IDLE = 0, PH_OBJ = 1, PH_NODE = 2, PH_TRI = 3, PH_DONE = 5,
 
 // Lane mask of a predicate; the intrinsic folds into the compare that produced the predicate.
 __device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// the per-lane boolean of a wave-uniform lane mask (free: the mask is used as the condition as it stands)
+__device__ __forceinline__ bool lanes_of(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 
 // ---- ray sources ------------------------------------------------------------------
 // Every source also names the time below which a hit ends the query early (stop_time): -inf for closest-hit
@@ -585,6 +587,13 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
 #define END (KEEP ? end_v : first_end)
     GBytePtr slab_v = nullptr;      // the current mesh's hot-node array (slab + 64); everything else is an offset
     bool pre = false;             // this ray/mesh pair may use the single-precision pre-test
+    uint64_t m_notpre = ~0ull, m_notfast = ~0ull;   // lanes whose ray may not use the pre-test / the division-free test
+    // the full f64 node `index` of the current mesh; the index is laundered so that the address arithmetic stays in
+    // the rare branches that need it instead of being hoisted into every node step
+    auto full_node = [&](uint32_t index) {
+        asm volatile("" : "+v"(index));
+        return (GNodePtr)(SLAB + (uint64_t)END * sizeof(HotNode)) + index;
+    };
     double t_stop = -kInf;        // sources with kEarlyStop: a held hit below this time ends the walk of a mesh
     // single-precision ray for the pre-test: reciprocal direction, -(origin * reciprocal), error bound, and the
     // holder's bound rounded to f32
@@ -814,6 +823,8 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
             }
             m_node = wave_ballot(phase == PH_NODE);
             m_tri = wave_ballot(phase == PH_TRI);
+            if (PRE) m_notpre = wave_ballot(!pre);
+            if (!PRE) m_notfast = wave_ballot(!fast);
             if (STATS) tk_obj += __builtin_amdgcn_s_memtime() - tk0;
         }
 
@@ -830,74 +841,87 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                 st_node_l += (uint32_t)__popcll(m_node);
                 tk0 = __builtin_amdgcn_s_memtime();
             }
-            bool slow_any = PRE || wave_ballot(phase == PH_NODE && !fast) != 0;
-            bool pre_all = PRE && wave_ballot(phase == PH_NODE && !pre) == 0;
-            if (phase == PH_NODE) {
-                GNodePtr node = (GNodePtr)(SLAB + (uint64_t)END * sizeof(HotNode)) + cur;   // the full f64 node
-                bool go;
-                uint32_t skip, leaf_ref;
-                if (pre_all) {
-                    // single-precision pre-test on the 32-byte companion node
-                    typedef const vu4 __attribute__((address_space(1))) *U4;
-                    U4 hp = (U4)(SLAB + (uint64_t)cur * sizeof(HotNode));
-                    vu4 h0 = hp[0], h1 = hp[1];
-                    vf2 cx = {__uint_as_float(h0.x), __uint_as_float(h0.y)};   // lo.x, hi.x
-                    vf2 cy = {__uint_as_float(h0.z), __uint_as_float(h0.w)};
-                    vf2 cz = {__uint_as_float(h1.x), __uint_as_float(h1.y)};
-                    skip = h1.z;
-                    leaf_ref = h1.w;
-                    if (COUNT) ctr.nodes++;
-                    vf2 qx = __builtin_elementwise_fma(cx, (vf2){r32x, r32x}, (vf2){np32x, np32x});
-                    vf2 qy = __builtin_elementwise_fma(cy, (vf2){r32y, r32y}, (vf2){np32y, np32y});
-                    vf2 qz = __builtin_elementwise_fma(cz, (vf2){r32z, r32z}, (vf2){np32z, np32z});
-                    float mn = hw_max0f(hw_max3f(hw_minf(qx.x, qx.y), hw_minf(qy.x, qy.y), hw_minf(qz.x, qz.y)));
-                    float mx = hw_min3f(hw_maxf(qx.x, qx.y), hw_maxf(qy.x, qy.y), hw_maxf(qz.x, qz.y));
-                    float g1 = mx - mn;                                   // NaN when every axis is skipped
-                    float g2 = b32 - mn;                                  // NaN when the held time is NaN
-                    bool yes = g1 > e2 && g2 > e2;
-                    bool no = g1 < -e2 || g2 < -e2;
-                    go = yes;
-                    if (wave_ballot(!(yes || no)) != 0) {
-                        if (STATS) {
-                            st_amb++;
-                            st_amb_l += (uint32_t)__popcll(wave_ballot(!(yes || no)));
-                        }
-                        if (!(yes || no)) {      // too close to call in single precision: the exact test decides
-                            V3 lo, hi;
-                            uint4 tail;
-                            load_node_g(node, lo, hi, tail);
-                            go = box_hit_div(lo, hi, load_in(), h.t);
-                        }
+            // Lane sets are kept as scalar masks and combined with scalar instructions: a vote over a boolean that is
+            // not itself a comparison costs two vector instructions, a vote over a comparison none.
+            const bool slow_any = PRE || (m_node & m_notfast) != 0;
+            const bool pre_all = PRE && (m_node & m_notpre) == 0;
+            // The step has no divergent branch on its common path: every lane executes it (a vector instruction costs
+            // the same with 46 or 64 lanes enabled), lanes outside m_node read the root's record -- one more cache
+            // line per load -- and keep their state through the selects.  That keeps every mask wave-uniform.
+            const bool act = lanes_of(m_node);
+            bool go_exact = false;
+            uint64_t m_go;
+            uint32_t skip, leaf_ref;
+            if (pre_all) {
+                // single-precision pre-test on the 32-byte companion node
+                typedef const vu4 __attribute__((address_space(1))) *U4;
+                U4 hp = (U4)((KEEP && !act ? first_slab : SLAB) + (uint64_t)(act ? cur : 0u) * sizeof(HotNode));
+                vu4 h0 = hp[0], h1 = hp[1];
+                vf2 cx = {__uint_as_float(h0.x), __uint_as_float(h0.y)};   // lo.x, hi.x
+                vf2 cy = {__uint_as_float(h0.z), __uint_as_float(h0.w)};
+                vf2 cz = {__uint_as_float(h1.x), __uint_as_float(h1.y)};
+                skip = h1.z;
+                leaf_ref = h1.w;
+                vf2 qx = __builtin_elementwise_fma(cx, (vf2){r32x, r32x}, (vf2){np32x, np32x});
+                vf2 qy = __builtin_elementwise_fma(cy, (vf2){r32y, r32y}, (vf2){np32y, np32y});
+                vf2 qz = __builtin_elementwise_fma(cz, (vf2){r32z, r32z}, (vf2){np32z, np32z});
+                float mn = hw_max0f(hw_max3f(hw_minf(qx.x, qx.y), hw_minf(qy.x, qy.y), hw_minf(qz.x, qz.y)));
+                float mx = hw_min3f(hw_maxf(qx.x, qx.y), hw_maxf(qy.x, qy.y), hw_maxf(qz.x, qz.y));
+                float g1 = mx - mn;                                   // NaN when every axis is skipped
+                float g2 = b32 - mn;                                  // NaN when the held time is NaN
+                const uint64_t m_yes = wave_ballot(g1 > e2) & wave_ballot(g2 > e2) & m_node;
+                const uint64_t m_no = wave_ballot(g1 < -e2) | wave_ballot(g2 < -e2);
+                const uint64_t m_amb = m_node & ~(m_yes | m_no);      // NaNs land here: neither proven
+                m_go = m_yes;
+                if (m_amb != 0) {
+                    if (STATS) {
+                        st_amb++;
+                        st_amb_l += (uint32_t)__popcll(m_amb);
                     }
-                } else {
+                    if (lanes_of(m_amb)) {       // too close to call in single precision: the exact test decides
+                        V3 lo, hi;
+                        uint4 tail;
+                        load_node_g(full_node(cur), lo, hi, tail);
+                        go_exact = box_hit_div(lo, hi, load_in(), h.t);
+                    }
+                    m_go |= wave_ballot(go_exact);
+                }
+            } else {
+                skip = 0;
+                leaf_ref = 0xFFFFFFFFu;
+                if (act) {
                     V3 lo, hi;
                     uint4 tail;
-                    load_node_g(node, lo, hi, tail);
-                    if (COUNT) ctr.nodes++;
+                    load_node_g(full_node(cur), lo, hi, tail);
                     const Ray in = load_in();
-                    go = slow_any ? box_hit_div(lo, hi, in, h.t) : box_hit_fast(lo, hi, in, rcp, h.t);
+                    go_exact = slow_any ? box_hit_div(lo, hi, in, h.t) : box_hit_fast(lo, hi, in, rcp, h.t);
                     skip = tail.x;
                     leaf_ref = tail.w == 0 ? 0xFFFFFFFFu : (tail.w == 1 ? tail.z : 0x80000000u);
                 }
-                // branch-free successor: a passed box goes on to the next array element, a failed one to the skip link
-                const bool to_leaf = go && leaf_ref != 0xFFFFFFFFu;
-                const uint32_t node_index = cur;
-                cur = go ? cur + 1 : skip;
-                leaf_cur = to_leaf ? leaf_ref : leaf_cur;
-                phase = to_leaf ? PH_TRI : PH_NODE;
-                if (wave_ballot(to_leaf && (leaf_ref & 0x80000000u)) != 0) {    // rare: a node with several leaves
-                    if (to_leaf && (leaf_ref & 0x80000000u)) {               // the range lives in the full node
-                        typedef const vu4 __attribute__((address_space(1))) *U4;
-                        vu4 t = ((U4)((GNodePtr)(SLAB + (uint64_t)END * sizeof(HotNode)) + node_index))[3];
-                        leaf_cur = t.z | 0x80000000u;
-                    }
-                }
-                if (phase == PH_NODE && cur >= END) phase = PH_DONE;   // traversal finished (resolved below)
+                m_go = wave_ballot(go_exact);
             }
-            m_tri = wave_ballot(phase == PH_TRI);
+            if (COUNT) ctr.nodes += act ? 1u : 0u;
+            // branch-free successor: a passed box goes on to the next array element, a failed one to the skip link
+            const uint64_t m_to_leaf = m_go & wave_ballot(leaf_ref != 0xFFFFFFFFu);
+            const bool to_leaf = lanes_of(m_to_leaf);
+            const uint32_t node_index = cur;
+            cur = lanes_of(m_go) ? cur + 1 : (act ? skip : cur);
+            leaf_cur = to_leaf ? leaf_ref : leaf_cur;
+            // rare: a node with several leaves (bit 31 of the reference set, and not the "no leaf" pattern)
+            const uint64_t m_range = m_to_leaf & wave_ballot((int32_t)leaf_ref < -1);
+            if (m_range != 0) {
+                if (lanes_of(m_range)) {                                     // the range lives in the full node
+                    typedef const vu4 __attribute__((address_space(1))) *U4;
+                    vu4 t = ((U4)full_node(node_index))[3];
+                    leaf_cur = t.z | 0x80000000u;
+                }
+            }
+            const uint64_t m_end = wave_ballot(cur >= END) & m_node & ~m_to_leaf;   // traversal finished (resolved below)
+            phase = to_leaf ? PH_TRI : (lanes_of(m_end) ? PH_DONE : phase);
+            m_tri |= m_to_leaf;
+            m_node &= ~(m_to_leaf | m_end);
             if (STATS) tk_node += __builtin_amdgcn_s_memtime() - tk0;
             // go round again until a triangle step is due (finished lanes wait for the end of the burst)
-            m_node = wave_ballot(phase == PH_NODE);
             if ((uint32_t)__popcll(m_tri) >= tri_thr) break;
         }
 
