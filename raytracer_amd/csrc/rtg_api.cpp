@@ -510,6 +510,10 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) {
         ctx->tune.stats = value > 1 ? 1u : 0u;   // 2 = on, 1 = off (0 is rejected above as out of range)
         return RTG_OK;
     }
+    if (std::strcmp(key, "keep_state") == 0) {
+        ctx->tune.keep_state = value > 1 ? 1u : 0u;   // 2 = on, 1 = off
+        return RTG_OK;
+    }
     return fail(ctx, RTG_E_INVALID, "unknown option '%s'", key);
 }
 
@@ -1048,6 +1052,7 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
         if (desc->objects[i].material.has_dielectric || desc->objects[i].material2.has_dielectric) s->any_dielectric = true;
     s->dev.has_patches = 0;
     s->dev.any_f32_ok = 0;
+    s->dev.wide_mesh = 0;
     {
         std::vector<DevObject> meshes;
         uint32_t n_prims = 0;
@@ -1069,6 +1074,7 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
         if (o.kind == RTG_PATCHES) s->dev.has_patches = 1;
         if ((o.kind == RTG_MESH || o.kind == RTG_PATCHES) && o.mesh->dev.f32_ok) s->dev.any_f32_ok = 1;
         if ((o.kind == RTG_MESH || o.kind == RTG_PATCHES) && o.mesh->dev.n_nodes != 0) s->has_mesh = true;
+        if ((o.kind == RTG_MESH || o.kind == RTG_PATCHES) && o.mesh->dev.n_nodes >= (1u << 27)) s->dev.wide_mesh = 1;
     }
     *out = s;
     return RTG_OK;

@@ -117,6 +117,7 @@ struct DevScene {
     const DevObject *mesh_objects;
     uint32_t n_mesh_objects;
     uint32_t n_prims;            // spheres + planes in `objects`
+    uint32_t wide_mesh;          // some mesh has 2^27 nodes or more: 32-bit byte offsets into its node arrays overflow
 };
 
 // ------------------------------------------------------------------- math --

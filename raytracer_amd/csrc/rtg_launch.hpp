@@ -30,6 +30,7 @@ struct PhasedTuning {
     uint32_t max_blocks = 0;     // persistent grid in four-wave groups; 0 = as many as the GPU holds at once
     uint32_t pretest = 1;        // single-precision box pre-test with exact fallback
     uint32_t stats = 0;          // diagnostics build: tally steps and lanes per phase
+    uint32_t keep_state = 0;     // run the several-meshes build (per-lane tree base, outer ray kept) on any scene
     // when set, the persistent kernel's launch records its execution window (the dispatch's own begin and end
     // timestamps, what a profiler reports as the kernel's duration) in these events
     hipEvent_t time_start = nullptr, time_stop = nullptr;

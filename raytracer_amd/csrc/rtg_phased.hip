@@ -594,6 +594,9 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
         asm volatile("" : "+v"(index));
         return (GNodePtr)(SLAB + (uint64_t)END * sizeof(HotNode)) + index;
     };
+    // the first mesh's hot nodes as a raw buffer (base, size in bytes, 32-bit data)
+    const __amdgpu_buffer_rsrc_t hot_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)first_slab, 0, (int)(KEEP ? 0u : first_end * (uint32_t)sizeof(HotNode)), 0x00020000);
     double t_stop = -kInf;        // sources with kEarlyStop: a held hit below this time ends the walk of a mesh
     // single-precision ray for the pre-test: reciprocal direction, -(origin * reciprocal), error bound, and the
     // holder's bound rounded to f32
@@ -834,6 +837,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
 #pragma unroll 1
         for (int round = 0; round < RTG_ROUNDS; round++) {
         // ---- one box test per lane, repeated until a triangle step is due ----------------------
+        uint64_t m_done_burst = 0;       // during a burst the lanes' phases live in the masks; written back after it
 #pragma unroll 1
         for (int rep = 0; rep < RTG_NODE_BURST && m_node != 0; rep++) {
             if (STATS) {
@@ -855,8 +859,19 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
             if (pre_all) {
                 // single-precision pre-test on the 32-byte companion node
                 typedef const vu4 __attribute__((address_space(1))) *U4;
-                U4 hp = (U4)((KEEP && !act ? first_slab : SLAB) + (uint64_t)(act ? cur : 0u) * sizeof(HotNode));
-                vu4 h0 = hp[0], h1 = hp[1];
+                vu4 h0, h1;
+                if (KEEP) {
+                    U4 hp = (U4)((act ? slab_v : first_slab) + (uint64_t)(act ? cur : 0u) * sizeof(HotNode));
+                    h0 = hp[0];
+                    h1 = hp[1];
+                } else {
+                    // one mesh: buffer loads, whose address is a scalar base plus the lane's 32-bit byte offset -- no
+                    // 64-bit address arithmetic per lane (the launcher sends trees whose hot nodes span 4 GiB or more
+                    // to the KEEP build)
+                    const uint32_t off = (act ? cur : 0u) * (uint32_t)sizeof(HotNode);
+                    h0 = __builtin_amdgcn_raw_buffer_load_b128(hot_rsrc, off, 0, 0);
+                    h1 = __builtin_amdgcn_raw_buffer_load_b128(hot_rsrc, off + 16, 0, 0);
+                }
                 vf2 cx = {__uint_as_float(h0.x), __uint_as_float(h0.y)};   // lo.x, hi.x
                 vf2 cy = {__uint_as_float(h0.z), __uint_as_float(h0.w)};
                 vf2 cz = {__uint_as_float(h1.x), __uint_as_float(h1.y)};
@@ -867,10 +882,13 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                 vf2 qz = __builtin_elementwise_fma(cz, (vf2){r32z, r32z}, (vf2){np32z, np32z});
                 float mn = hw_max0f(hw_max3f(hw_minf(qx.x, qx.y), hw_minf(qy.x, qy.y), hw_minf(qz.x, qz.y)));
                 float mx = hw_min3f(hw_maxf(qx.x, qx.y), hw_maxf(qy.x, qy.y), hw_maxf(qz.x, qz.y));
-                float g1 = mx - mn;                                   // NaN when every axis is skipped
-                float g2 = b32 - mn;                                  // NaN when the held time is NaN
-                const uint64_t m_yes = wave_ballot(g1 > e2) & wave_ballot(g2 > e2) & m_node;
-                const uint64_t m_no = wave_ballot(g1 < -e2) | wave_ballot(g2 < -e2);
+                // The two margins g1 = mx - mn (the box's interval) and g2 = b32 - mn (the holder's bound) are only
+                // ever compared with the same thresholds, and rounding is monotonic, so their minimum is
+                // min(mx, b32) - mn: one subtraction.  The minimum is the NaN-propagating one: mx is NaN when every
+                // axis is skipped, b32 when the held time is NaN, and both must end up undecided.
+                const float g = __builtin_elementwise_minimum(mx, b32) - mn;
+                const uint64_t m_yes = wave_ballot(g > e2) & m_node;
+                const uint64_t m_no = wave_ballot(g < -e2);
                 const uint64_t m_amb = m_node & ~(m_yes | m_no);      // NaNs land here: neither proven
                 m_go = m_yes;
                 if (m_amb != 0) {
@@ -917,16 +935,17 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                 }
             }
             const uint64_t m_end = wave_ballot(cur >= END) & m_node & ~m_to_leaf;   // traversal finished (resolved below)
-            phase = to_leaf ? PH_TRI : (lanes_of(m_end) ? PH_DONE : phase);
+            m_done_burst |= m_end;
             m_tri |= m_to_leaf;
             m_node &= ~(m_to_leaf | m_end);
             if (STATS) tk_node += __builtin_amdgcn_s_memtime() - tk0;
             // go round again until a triangle step is due (finished lanes wait for the end of the burst)
             if ((uint32_t)__popcll(m_tri) >= tri_thr) break;
         }
+        phase = lanes_of(m_tri) ? PH_TRI : (lanes_of(m_done_burst) ? PH_DONE : phase);
 
         // ---- one triangle per waiting lane ----------------------------------------------
-        if (m_tri != 0 && ((uint32_t)__popcll(m_tri) >= tri_thr || wave_ballot(phase == PH_NODE) == 0)) {
+        if (m_tri != 0 && ((uint32_t)__popcll(m_tri) >= tri_thr || m_node == 0)) {
             if (STATS) {
                 st_tri++;
                 st_tri_l += (uint32_t)__popcll(m_tri);
@@ -1136,14 +1155,15 @@ static hipError_t launch_phased(hipStream_t stream, const DevScene &s, const Sou
     uint64_t want = (chunks + (kPhasedBlock / 64) - 1) / (kPhasedBlock / 64);
     // tune.max_blocks == 0: fill the GPU -- 256 CUs x waves per SIMD four-wave groups for the variant that will run
     const uint32_t fill = 256u * (uint32_t)phased_waves(Source::kFiveWaves, out_counters != nullptr, s.has_patches != 0,
-                                                        s.n_mesh_objects > 1, tune.stats != 0);
+                                                        s.n_mesh_objects > 1 || s.wide_mesh != 0 || tune.keep_state != 0,
+                                                        tune.stats != 0);
     uint64_t most = (uint64_t)(tune.max_blocks ? tune.max_blocks : fill) * per_group;
     uint32_t grid = (uint32_t)(want < most ? want : most);
     if (grid == 0) grid = 1;
     // the outer ray is needed again when there are several meshes; only then does the dynamic LDS hold it (9 cold
     // fields per lane instead of 3)
     const bool count = out_counters != nullptr;
-    const bool keep = s.n_mesh_objects > 1;
+    const bool keep = s.n_mesh_objects > 1 || s.wide_mesh != 0 || tune.keep_state != 0;
     const bool pre = tune.pretest && s.any_f32_ok;
     PhasedParams prm{tune.tri_min, tune.obj_min, tune.patch_tri_min};
     const size_t cold_bytes = (size_t)(keep ? 9 : 2) * kPhasedBlock * sizeof(double);

@@ -77,6 +77,39 @@ def test_mesh_scene_primary(gpu_ctx, traversal, with_normals):
     gpu_ctx.set_option("traversal", 2)
 
 
+def test_single_mesh_through_the_several_meshes_build(gpu_ctx):
+    """A mesh of 2^27 nodes or more is sent to the kernel build that carries 64-bit tree addresses per lane (the one
+    scenes with several meshes use); option keep_state forces that dispatch on an ordinary mesh."""
+    tris, xform = scenes.terrain(100, 100, seed=5)
+    bvh = rtg.HostBvh(tris)
+    objs, lights, view = scenes.mesh_scene_objects(xform)
+    pair = scenes.Pair(gpu_ctx, objs, {2: bvh})
+    bare_objs, _, _ = scenes.mesh_scene_objects(xform, with_default=False)
+    bare = scenes.Pair(gpu_ctx, bare_objs, {0: bvh})
+    w, h = 256, 160
+    rays = rtg.bench_mesh_rays(bvh.bounds(), 30000, seed=3)
+    rays[:, :3] /= 100.0                         # into the instance's world space
+    want_p, _, want_pc = pair.cpu.render_primary(view, w, h, counters=True)
+    want_b, _, want_bc = bare.cpu.trace(rays, counters=True)
+    lights = np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
+    want_rgb, _, _ = pair.cpu.render_frame(view, lights, w, h)
+    for keep in (1, 2):
+        gpu_ctx.set_option("keep_state", keep)
+        got_p, _, got_pc = pair.gpu.render_primary(view, w, h, counters=True)
+        _assert_hits_equal(got_p, want_p)
+        assert np.array_equal(got_pc, want_pc)
+        got_p, _, _ = pair.gpu.render_primary(view, w, h)              # the build without counters
+        _assert_hits_equal(got_p, want_p)
+        got_b, _, got_bc = bare.gpu.trace(rays, counters=True)
+        _assert_hits_equal(got_b, want_b)
+        assert np.array_equal(got_bc, want_bc)
+        got_b, _, _ = bare.gpu.trace(rays)
+        _assert_hits_equal(got_b, want_b)
+        got_rgb, _, _ = pair.gpu.render_frame(view, lights, w, h)      # shadow rays
+        assert not scenes.float_bits_differ(got_rgb, want_rgb).any()
+    gpu_ctx.set_option("keep_state", 1)
+
+
 @pytest.mark.parametrize("traversal", TRAVERSALS)
 def test_incoherent_batch_rays(gpu_ctx, traversal):
     """bench_mesh ray distribution (src/tree/benchmark.rs:15-27) against a bare mesh object."""
