@@ -389,12 +389,15 @@ struct WorkQueue {
     }
 };
 
-// The ray of the single-precision box pre-test: q32 = fma(c32, r32, -(o32 * r32)) differs from the reference's f64
-// plane time (c - o) / d by at most 2^-24 * (3|c| + 4|o|) * |r| (roundings of c, o, r to f32, of the product
-// o32 * r32 and of the fma); e2 = 16 * 2^-24 * (B + |o|) * |r|, B the mesh's largest |coordinate|, is twice what the
-// difference of two such times can be off by, and twice what a time minus the f32-rounded bound can be off by while
-// the bound is below 4 (B + |o|) |r| (above that the comparison is not close).  Axes with d = 0 get r32 = NaN, so
-// their plane times are NaN and drop out of the min/max exactly as in the f64 test.
+// The ray of the single-precision box pre-test.  q32 = fma(c32, r32, -(o32 * r32)) differs from the reference's f64
+// plane time (c - o) / d by at most E = 2^-24 * (3|c| + 4|o|) * |r| (to first order: c, o and r are each rounded to f32
+// once, the product o32 * r32 once, the fma once, and |q| <= (|c| + |o|) |r|).  Minimum and maximum are 1-Lipschitz, so
+// the entry and exit times carry the same bound with |c| replaced by B, the mesh's largest |coordinate|, and the
+// largest E of the three axes; the difference the pre-test looks at is therefore off by at most 2 E.  The holder's
+// bound rounded to f32 is off by 2^-24 |t|: below E whenever t <= 3 (B + |o|) |r|, and a larger t leaves the
+// comparison nowhere near a tie.  e2 = 2 E, inflated by 0.2 % for the roundings of this very computation and the
+// second-order terms.  Axes with d = 0 get r32 = NaN, so their plane times are NaN and drop out of the min/max exactly
+// as in the f64 test.
 struct PreRay {
     float rx, ry, rz, nx, ny, nz, e2;
 };
@@ -415,10 +418,11 @@ __device__ __forceinline__ PreRay pre_ray_from_reciprocals(const Ray &in, float 
     p.nx = -(ox * p.rx);
     p.ny = -(oy * p.ry);
     p.nz = -(oz * p.rz);
-    float ex = in.d.x == 0.0 ? 0.0f : (coord_max + __builtin_fabsf(ox)) * __builtin_fabsf(p.rx);
-    float ey = in.d.y == 0.0 ? 0.0f : (coord_max + __builtin_fabsf(oy)) * __builtin_fabsf(p.ry);
-    float ez = in.d.z == 0.0 ? 0.0f : (coord_max + __builtin_fabsf(oz)) * __builtin_fabsf(p.rz);
-    p.e2 = __builtin_fmaxf(ex, __builtin_fmaxf(ey, ez)) * 0x1p-20f;
+    const float b3 = 3.0f * coord_max;
+    float ex = in.d.x == 0.0 ? 0.0f : (b3 + 4.0f * __builtin_fabsf(ox)) * __builtin_fabsf(p.rx);
+    float ey = in.d.y == 0.0 ? 0.0f : (b3 + 4.0f * __builtin_fabsf(oy)) * __builtin_fabsf(p.ry);
+    float ez = in.d.z == 0.0 ? 0.0f : (b3 + 4.0f * __builtin_fabsf(oz)) * __builtin_fabsf(p.rz);
+    p.e2 = __builtin_fmaxf(ex, __builtin_fmaxf(ey, ez)) * (0x1p-23f * 1.002f);
     return p;
 }
 __device__ __forceinline__ PreRay make_pre_ray(const Ray &in, float coord_max) {
