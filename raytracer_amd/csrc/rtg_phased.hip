@@ -88,12 +88,15 @@ struct PrimarySource {
         out_index = (uint64_t)py * tile.w + px;
         return true;
     }
-    // output slot of an item that make() accepts
-    __device__ __forceinline__ uint64_t slot_of(uint64_t item) const {
-        uint32_t px, py;
-        uint64_t out_index = 0;
-        (void)locate(item, px, py, out_index);
-        return out_index;
+    // output slot of an item that make() accepts; `chunk_first` is the output slot of the chunk's first item (the
+    // tile's top left pixel), worked out once per 64-item chunk so that no lane divides by the tile count again
+    __device__ __forceinline__ uint64_t chunk_origin(uint32_t chunk) const {
+        uint32_t ty = chunk / tiles_x, tx = chunk - ty * tiles_x;
+        return (uint64_t)(ty * 8u) * tile.w + tx * 8u;
+    }
+    __device__ __forceinline__ uint64_t slot_of(uint64_t item, uint64_t chunk_first) const {
+        uint32_t l = (uint32_t)item & 63u;
+        return chunk_first + (uint64_t)(l >> 3) * tile.w + (l & 7u);
     }
     __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
         uint32_t px, py;
@@ -108,7 +111,8 @@ struct BatchSource {
     __device__ __forceinline__ double stop_time(uint64_t) const { return -kInf; }
     const double *rays6;
     uint64_t n;
-    __device__ __forceinline__ uint64_t slot_of(uint64_t item) const { return item; }
+    __device__ __forceinline__ uint64_t chunk_origin(uint32_t) const { return 0; }
+    __device__ __forceinline__ uint64_t slot_of(uint64_t item, uint64_t) const { return item; }
     __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
         if (item >= n) return false;
         const double2 *q = reinterpret_cast<const double2 *>(rays6 + item * 6);
@@ -144,7 +148,8 @@ struct ShadowSource {
         (void)shadow_query(lights[l], ld3(pt.position), ld3(pt.inter_normal), q);
         return q.dis;
     }
-    __device__ __forceinline__ uint64_t slot_of(uint64_t item) const { return item; }
+    __device__ __forceinline__ uint64_t chunk_origin(uint32_t) const { return 0; }
+    __device__ __forceinline__ uint64_t slot_of(uint64_t item, uint64_t) const { return item; }
     __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
         uint64_t l = item / n_points, p = item - l * n_points;
         if (l >= n_lights) return false;
@@ -170,7 +175,8 @@ struct ShadowAndBatchSource {
     __device__ __forceinline__ double stop_time(uint64_t item) const {
         return item < n_shadow ? shadow.stop_time(item) : -kInf;
     }
-    __device__ __forceinline__ uint64_t slot_of(uint64_t item) const { return item; }
+    __device__ __forceinline__ uint64_t chunk_origin(uint32_t) const { return 0; }
+    __device__ __forceinline__ uint64_t slot_of(uint64_t item, uint64_t) const { return item; }
     __device__ __forceinline__ bool make(uint64_t item, Ray &ray, uint64_t &out_index) const {
         bool ok = item < n_shadow ? shadow.make(item, ray, out_index) : batch.make(item - n_shadow, ray, out_index);
         out_index = item;
@@ -525,6 +531,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
     wq.tried = 0;
     bool exhausted = false;       // wave-uniform: every work range has been drained
     uint64_t chunk_base = 0;      // wave-uniform
+    uint64_t chunk_first = 0;     // output slot of the chunk's first item (wave-uniform)
     uint32_t chunk_left = 0;      // wave-uniform
 
     // per-lane state
@@ -695,6 +702,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                     }
                     chunk_base = (uint64_t)chunk << 6;
                     chunk_left = 64;
+                    chunk_first = src.chunk_origin(chunk);
                     {                       // every lane prepares one ray of the chunk
                         const DevObject &o0 = s.mesh_objects[0];
                         Ray ray;
@@ -741,7 +749,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                             if (Source::kEarlyStop) {
                                 t_stop = __longlong_as_double((long long)(((uint64_t)STG_U(slot, 5) << 32) | STG_U(slot, 4)));
                             }
-                            uint64_t out_index = src.slot_of(item);
+                            uint64_t out_index = src.slot_of(item, chunk_first);
                             if (need_outer) {
                                 Ray ray;
                                 (void)src.make(item, ray, out_index);
