@@ -94,7 +94,7 @@ __device__ __forceinline__ D3 dray_pos(const RayD &r, D2 t) { return r.o + r.d *
 __device__ __forceinline__ RayD dbounce(const D3 &o, const D3 &d) { return RayD{o + d * dconst(1e-5), d}; }
 
 // Mat4 * (p, w), rows 0..2, the matrix cast to Der (geo/transform.rs:60-80, math/mat.rs:155-160,180-183)
-__device__ __noinline__ D3 dmat4_apply(const double *m, const D3 &p, double w) {
+__device__ __forceinline__ D3 dmat4_apply(const double *m, const D3 &p, double w) {
     const D2 v[4] = {p.x, p.y, p.z, dconst(w)};
     D2 out[3];
     for (int i = 0; i < 3; i++) {
@@ -104,7 +104,7 @@ __device__ __noinline__ D3 dmat4_apply(const double *m, const D3 &p, double w) {
     }
     return d3(out[0], out[1], out[2]);
 }
-__device__ __noinline__ D3 dforward_norm(const double *m, const D3 &n) {
+__device__ __forceinline__ D3 dforward_norm(const double *m, const D3 &n) {
     const D2 v[3] = {n.x, n.y, n.z};
     D2 out[3];
     for (int i = 0; i < 3; i++) {
@@ -125,7 +125,7 @@ __device__ __forceinline__ D3 zenith_y_into_normal(double zenith, double y) {
 }
 
 // roots 0.0.7 find_roots_quadratic over Der, consumed as in geo/sphere.rs:89-93
-__device__ __noinline__ bool dquadratic_first_nonneg(D2 a2, D2 a1, D2 a0, D2 &t_out) {
+__device__ __forceinline__ bool dquadratic_first_nonneg(D2 a2, D2 a1, D2 a0, D2 &t_out) {
     const D2 zero = dconst(0.0);
     D2 r0 = zero, r1 = zero;
     int n = 0;
@@ -208,7 +208,7 @@ struct PointD {
 // TransformObject<AnyObject>::raycast over Der (render/transform_object.rs:17-28, any_object.rs:15-23) for one
 // object; `leaf` names the triangle of a mesh (Bvh::raycast with a manifold, tree/bvh.rs:108-111: that triangle
 // alone, tested without the rejections, geo/triangle.rs:54-82 with manifold == true).
-__device__ __noinline__ bool object_eval(const DevObject &o, uint32_t leaf, uint64_t n_leaves, const RayD &outer, PointD &out) {
+__device__ __forceinline__ bool object_eval(const DevObject &o, uint32_t leaf, uint64_t n_leaves, const RayD &outer, PointD &out) {
     RayD in{dmat4_apply(o.reverse, outer.o, 1.0), dmat4_apply(o.reverse, outer.d, 0.0)};
     const D2 zero = dconst(0.0);
     D3 gn;
@@ -268,7 +268,7 @@ __device__ __noinline__ bool object_eval(const DevObject &o, uint32_t leaf, uint
 }
 
 // Dielectric::new over Der (render/dielectric.rs:13-52): the outgoing direction of the requested mode
-__device__ __noinline__ bool dielectric_dir(const D3 &inc_in, const D3 &signed_norm, double n1, double n2, bool refract, D3 &out) {
+__device__ __forceinline__ bool dielectric_dir(const D3 &inc_in, const D3 &signed_norm, double n1, double n2, bool refract, D3 &out) {
     const D2 zero = dconst(0.0), one = dconst(1.0);
     D3 inc = dnormalize(inc_in);
     D2 dt = ddot(inc, signed_norm);

@@ -49,6 +49,14 @@ for k in (1, 3, 16):
 for samples, steps in ((3, 5), (3, 0), (1, 5)):
     timed(f"caustic term, {pts.shape[0]} points, {samples} samples, {steps} steps", lambda: scene.indirect_irrad(pm, pts, samples, steps, 1e-5),
           pts.shape[0] * samples, "pairs")
+import torch  # noqa: E402
+d_pts = torch.from_numpy(pts.view(np.uint8).reshape(-1)).cuda()
+d_rgb = torch.empty(pts.shape[0] * 3, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+for samples, steps in ((3, 5), (3, 0)):
+    timed(f"caustic term, device-resident, {samples} samples, {steps} steps",
+          lambda: scene.indirect_irrad_raw(pm, d_pts.data_ptr(), pts.shape[0], samples, steps, 1e-5, d_rgb.data_ptr()),
+          pts.shape[0] * samples, "pairs")
 timed(f"frame {side}x{side} without photons", lambda: scene.render_frame(view, lights, side, side, hits=False), side * side, "pixels")
 timed(f"frame {side}x{side} with the photon term", lambda: scene.render_frame_photons(view, lights, pm, side, side), side * side, "pixels")
 
