@@ -223,26 +223,40 @@ int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_light
 
     const void *d_lights = nullptr;
     if ((rc = api_input(ctx, "photon_lights", lights, (size_t)n_lights * sizeof(rtg_light), &d_lights)) != RTG_OK) return rc;
-    const uint64_t batch = 1ull << 18;                       // rays per rtg_trace_paths call
+    const uint64_t batch = 1ull << 19;                       // rays per rtg_trace_paths call (1.1 GB of path records at depth 4)
     const uint64_t per_ray = (1ull << max_depth) - 1;        // paths a ray can have
     std::vector<double> rays;
     uint64_t total = 0;
     for (uint64_t first = 0; first < n_rays; first += batch) {
         const uint64_t m = std::min(batch, n_rays - first);
         rays.resize((size_t)m * 6);
-        for (uint64_t i = 0; i < m; i++) {
-            const uint64_t r = first + i;
-            const rtg_light &light = lights[r / count_per_light];
-            // ZenithY::into_normal (src/geo/sphere.rs:29-34); Ray::new(light.sphere.orig(), ..) (renderer.rs:123)
-            const double zenith = dirs2[r * 2], y = dirs2[r * 2 + 1];
-            const double radius = std::sqrt(1.0 - y * y);
-            double *w = &rays[(size_t)i * 6];
-            w[0] = light.position[0];
-            w[1] = light.position[1];
-            w[2] = light.position[2];
-            w[3] = libm_cos(zenith) * radius;
-            w[4] = y;
-            w[5] = libm_sin(zenith) * radius;
+        // ZenithY::into_normal (src/geo/sphere.rs:29-34); Ray::new(light.sphere.orig(), ..) (renderer.rs:123): two libm
+        // calls and a square root per direction, spread over the host's cores
+        auto make_rays = [&](uint64_t begin, uint64_t end) {
+            for (uint64_t i = begin; i < end; i++) {
+                const uint64_t r = first + i;
+                const rtg_light &light = lights[r / count_per_light];
+                const double zenith = dirs2[r * 2], y = dirs2[r * 2 + 1];
+                const double radius = std::sqrt(1.0 - y * y);
+                double *w = &rays[(size_t)i * 6];
+                w[0] = light.position[0];
+                w[1] = light.position[1];
+                w[2] = light.position[2];
+                w[3] = libm_cos(zenith) * radius;
+                w[4] = y;
+                w[5] = libm_sin(zenith) * radius;
+            }
+        };
+        {
+            unsigned n_threads = std::thread::hardware_concurrency();
+            n_threads = n_threads == 0 ? 1u : (n_threads > 16u ? 16u : n_threads);
+            if (m < 4096) n_threads = 1;
+            std::vector<std::thread> pool;
+            const uint64_t per = (m + n_threads - 1) / n_threads;
+            for (unsigned t = 1; t < n_threads; t++)
+                if (t * per < m) pool.emplace_back(make_rays, t * per, std::min(m, (t + 1) * per));
+            make_rays(0, std::min(m, per));
+            for (auto &th : pool) th.join();
         }
         void *d_paths = nullptr;
         if ((rc = api_scratch(ctx, "photon_paths", (size_t)(m * per_ray) * sizeof(rtg_path), &d_paths)) != RTG_OK) return rc;

@@ -141,7 +141,7 @@ def test_photon_pass_matches_the_oracle(gpu_ctx):
     assert got.shape[0] > 1000
     _photon_fields_equal(got, want)
     # more rays than one batch of the pass holds, through the other traversals as well
-    big = np.stack([rtg.fibonacci_zenith_y(300_000, seed=7)])
+    big = np.stack([rtg.fibonacci_zenith_y(600_000, seed=7)])
     want = pair.cpu.photons_emit(lights[:1], big)
     for traversal in (2, 1, 0):
         gpu_ctx.set_option("traversal", traversal)
