@@ -14,6 +14,9 @@
  *    is available from rtg_last_error().  The reference panics instead
  *    (e.g. src/render/object.rs:45-46, src/tree/bvh.rs:109); panics must not
  *    cross a C ABI, so they become error codes.
+ *    No C++ exception leaves the library either: every entry point stops them
+ *    at the boundary (RTG_E_NOMEM for a failed host allocation, RTG_E_INTERNAL
+ *    otherwise).
  *  - "no hit" is not an error: object = leaf = RTG_NONE, t = +inf.
  *  - all arithmetic is IEEE binary64 without contraction, in the reference's
  *    operation order, so hit ids and hit times are bit-identical to the CPU
@@ -47,6 +50,7 @@ extern "C" {
 #define RTG_E_NODEVICE (-4)    /* no usable gfx950 device                 */
 #define RTG_E_UNSUPPORTED (-5) /* valid request the build does not cover  */
 #define RTG_E_LIMIT (-6)       /* size beyond a documented maximum        */
+#define RTG_E_INTERNAL (-7)    /* a C++ exception other than bad_alloc was stopped at the boundary */
 
 #define RTG_NONE 0xFFFFFFFFu
 

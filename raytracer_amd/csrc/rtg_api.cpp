@@ -235,17 +235,7 @@ void invert4(const double *m, double *n) {
 
 // Splits [0, n) over a few host threads (mesh creation touches every node and triangle of trees with tens of
 // millions of records).
-template <class F> void parallel_ranges(size_t n, F f) {
-    unsigned t = std::thread::hardware_concurrency();
-    if (t > 16) t = 16;
-    if (t < 2 || n < (1u << 16)) {
-        f((size_t)0, n);
-        return;
-    }
-    std::vector<std::thread> pool;
-    for (unsigned w = 0; w < t; w++) pool.emplace_back([=]() { f(n * w / t, n * (w + 1) / t); });
-    for (auto &th : pool) th.join();
-}
+template <class F> void parallel_ranges(size_t n, F f) { api_parallel_ranges(n, (size_t)1 << 15, f); }
 
 // Walks the caller's tree from the root: checks every range, rejects shared or
 // cyclic nodes, and emits (a) the reference-order node array with a
@@ -365,6 +355,27 @@ int api_fail(rtg_ctx *ctx, int code, const char *fmt, ...) {
     set_error(ctx, buf);
     return code;
 }
+int api_caught(rtg_ctx *ctx, const char *function) noexcept {
+    int code = RTG_E_INTERNAL;
+    char text[256];
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        code = RTG_E_NOMEM;
+        snprintf(text, sizeof(text), "%s: out of host memory", function);
+    } catch (const std::exception &e) {
+        code = RTG_E_NOMEM;                 // what the standard library throws here is about resources (threads, locks)
+        snprintf(text, sizeof(text), "%s: %s", function, e.what());
+    } catch (...) {
+        snprintf(text, sizeof(text), "%s: unexpected exception", function);
+    }
+    try {
+        set_error(ctx, text);
+    } catch (...) {
+        // the message is lost, the code is not
+    }
+    return code;
+}
 bool api_is_device_pointer(const void *p) { return is_device_pointer(p); }
 int api_scratch(rtg_ctx *ctx, const char *name, size_t bytes, void **out) { return scratch_get(ctx, name, bytes, out); }
 int api_input(rtg_ctx *ctx, const char *name, const void *user, size_t bytes, const void **dev) {
@@ -393,7 +404,7 @@ extern "C" {
 
 const char *rtg_version(void) { return "rtg 0.1 gfx950"; }
 
-int rtg_ctx_create(int hip_device, rtg_ctx **out) {
+int rtg_ctx_create(int hip_device, rtg_ctx **out) try {
     if (!out) return fail(nullptr, RTG_E_INVALID, "rtg_ctx_create: out is null");
     *out = nullptr;
     int count = 0;
@@ -424,6 +435,8 @@ int rtg_ctx_create(int hip_device, rtg_ctx **out) {
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return RTG_OK;
+} catch (...) {
+    return api_caught(nullptr, "rtg_ctx_create");
 }
 
 void rtg_ctx_destroy(rtg_ctx *ctx) {
@@ -446,22 +459,26 @@ void rtg_ctx_destroy(rtg_ctx *ctx) {
 
 const char *rtg_last_error(rtg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-int rtg_ctx_set_stream(rtg_ctx *ctx, void *hip_stream) {
+int rtg_ctx_set_stream(rtg_ctx *ctx, void *hip_stream) try {
     if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return RTG_OK;
+} catch (...) {
+    return api_caught(ctx, "rtg_ctx_set_stream");
 }
 void *rtg_ctx_get_stream(rtg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
-int rtg_ctx_synchronize(rtg_ctx *ctx) {
+int rtg_ctx_synchronize(rtg_ctx *ctx) try {
     if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
     int rc = bind_device(ctx);
     if (rc != RTG_OK) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTG_OK;
+} catch (...) {
+    return api_caught(ctx, "rtg_ctx_synchronize");
 }
 
-int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) {
+int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) try {
     if (!ctx || !key) return fail(ctx, RTG_E_INVALID, "null ctx or key");
     if (std::strcmp(key, "traversal") == 0) {
         if (value < 0 || value > 2)
@@ -515,9 +532,11 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) {
         return RTG_OK;
     }
     return fail(ctx, RTG_E_INVALID, "unknown option '%s'", key);
+} catch (...) {
+    return api_caught(ctx, "rtg_ctx_set_option");
 }
 
-int rtg_ctx_kernel_time(rtg_ctx *ctx, double *total_ms, uint64_t *launches) {
+int rtg_ctx_kernel_time(rtg_ctx *ctx, double *total_ms, uint64_t *launches) try {
     if (!ctx || !total_ms || !launches) return fail(ctx, RTG_E_INVALID, "null argument");
     *total_ms = 0.0;
     *launches = 0;
@@ -542,9 +561,11 @@ int rtg_ctx_kernel_time(rtg_ctx *ctx, double *total_ms, uint64_t *launches) {
     if (first_error != hipSuccess)
         return fail(ctx, RTG_E_HIP, "rtg_ctx_kernel_time: a launch's events were never filled: %s", hipGetErrorString(first_error));
     return RTG_OK;
+} catch (...) {
+    return api_caught(ctx, "rtg_ctx_kernel_time");
 }
 
-int rtg_ctx_debug_stats(rtg_ctx *ctx, uint32_t out[16]) {
+int rtg_ctx_debug_stats(rtg_ctx *ctx, uint32_t out[16]) try {
     if (!ctx || !out) return fail(ctx, RTG_E_INVALID, "null argument");
     int rc = bind_device(ctx);
     if (rc != RTG_OK) return rc;
@@ -553,9 +574,11 @@ int rtg_ctx_debug_stats(rtg_ctx *ctx, uint32_t out[16]) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, (const uint32_t *)it->second.ptr + 8 * 32, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return RTG_OK;
+} catch (...) {
+    return api_caught(ctx, "rtg_ctx_debug_stats");
 }
 
-int rtg_selftest_division(rtg_ctx *ctx, uint64_t seed, uint64_t n_pairs, uint32_t family, uint64_t out[3]) {
+int rtg_selftest_division(rtg_ctx *ctx, uint64_t seed, uint64_t n_pairs, uint32_t family, uint64_t out[3]) try {
     if (!ctx || !out) return fail(ctx, RTG_E_INVALID, "null argument");
     if (family > 3) return fail(ctx, RTG_E_INVALID, "family must be 0..3");
     int rc = bind_device(ctx);
@@ -569,9 +592,11 @@ int rtg_selftest_division(rtg_ctx *ctx, uint64_t seed, uint64_t n_pairs, uint32_
     HIP_TRY(ctx, hipMemcpyAsync(out, d, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTG_OK;
+} catch (...) {
+    return api_caught(ctx, "rtg_selftest_division");
 }
 
-int rtg_transform_from_forward(const double forward[16], rtg_transform *out) {
+int rtg_transform_from_forward(const double forward[16], rtg_transform *out) try {
     if (!forward || !out) return fail(nullptr, RTG_E_INVALID, "null argument");
     std::memcpy(out->forward, forward, sizeof(out->forward));
     invert4(forward, out->reverse);
@@ -580,9 +605,11 @@ int rtg_transform_from_forward(const double forward[16], rtg_transform *out) {
         for (int j = 0; j < 3; j++) reverse_norm[i * 3 + j] = forward[j * 4 + i];
     invert3(reverse_norm, out->forward_norm);
     return RTG_OK;
+} catch (...) {
+    return api_caught(nullptr, "rtg_transform_from_forward");
 }
 
-int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) {
+int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) try {
     if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
     if (!bvh || !out) return fail(ctx, RTG_E_INVALID, "rtg_mesh_create: null argument");
     *out = nullptr;
@@ -706,6 +733,8 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) {
     m->dev.coord_max = std::nextafter((float)cmax, std::numeric_limits<float>::infinity());
     *out = m;
     return RTG_OK;
+} catch (...) {
+    return api_caught(ctx, "rtg_mesh_create");
 }
 
 void rtg_mesh_destroy(rtg_mesh *m) {
@@ -720,7 +749,7 @@ void rtg_mesh_destroy(rtg_mesh *m) {
     delete m;
 }
 
-int rtg_mesh_create_patches(rtg_ctx *ctx, const rtg_bvh *bvh, const rtg_patch_set *ps, rtg_mesh **out) {
+int rtg_mesh_create_patches(rtg_ctx *ctx, const rtg_bvh *bvh, const rtg_patch_set *ps, rtg_mesh **out) try {
     if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
     if (!bvh || !ps || !out) return fail(ctx, RTG_E_INVALID, "rtg_mesh_create_patches: null argument");
     *out = nullptr;
@@ -759,10 +788,12 @@ int rtg_mesh_create_patches(rtg_ctx *ctx, const rtg_bvh *bvh, const rtg_patch_se
     m->dev.newton_steps = ps->newton_steps;
     *out = m;
     return RTG_OK;
+} catch (...) {
+    return api_caught(ctx, "rtg_mesh_create_patches");
 }
 
 int rtg_mesh_build(rtg_ctx *ctx, const rtg_tri *triangles, uint64_t n_triangles, const double *vertex_normals,
-                   rtg_mesh **out) {
+                   rtg_mesh **out) try {
     if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
     if (!out || (n_triangles && !triangles)) return fail(ctx, RTG_E_INVALID, "rtg_mesh_build: null argument");
     *out = nullptr;
@@ -856,10 +887,12 @@ int rtg_mesh_build(rtg_ctx *ctx, const rtg_tri *triangles, uint64_t n_triangles,
     m->dev.coord_max = std::nextafter((float)built.coord_max, std::numeric_limits<float>::infinity());
     *out = m;
     return RTG_OK;
+} catch (...) {
+    return api_caught(ctx, "rtg_mesh_build");
 }
 
 int rtg_mesh_build_patches(rtg_ctx *ctx, const rtg_tri *facets, uint64_t n_facets, const rtg_patch_set *ps,
-                           rtg_mesh **out) {
+                           rtg_mesh **out) try {
     if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
     if (!facets || !ps || !out) return fail(ctx, RTG_E_INVALID, "rtg_mesh_build_patches: null argument");
     *out = nullptr;
@@ -915,18 +948,22 @@ int rtg_mesh_build_patches(rtg_ctx *ctx, const rtg_tri *facets, uint64_t n_facet
     m->dev.newton_steps = ps->newton_steps;
     *out = m;
     return RTG_OK;
+} catch (...) {
+    return api_caught(ctx, "rtg_mesh_build_patches");
 }
 
-int rtg_mesh_sizes(const rtg_mesh *mesh, uint64_t *n_nodes, uint64_t *n_leaves, uint32_t *root, uint32_t *depth) {
+int rtg_mesh_sizes(const rtg_mesh *mesh, uint64_t *n_nodes, uint64_t *n_leaves, uint32_t *root, uint32_t *depth) try {
     if (!mesh) return fail(nullptr, RTG_E_INVALID, "null mesh");
     if (n_nodes) *n_nodes = mesh->dev.n_nodes;
     if (n_leaves) *n_leaves = mesh->n_leaves;
     if (root) *root = mesh->dev.root;
     if (depth) *depth = mesh->dev.depth;
     return RTG_OK;
+} catch (...) {
+    return api_caught(nullptr, "rtg_mesh_sizes");
 }
 
-int rtg_mesh_read_bvh(const rtg_mesh *mesh, rtg_bvh_node *nodes, rtg_tri *leaves, uint32_t *leaf_source) {
+int rtg_mesh_read_bvh(const rtg_mesh *mesh, rtg_bvh_node *nodes, rtg_tri *leaves, uint32_t *leaf_source) try {
     if (!mesh) return fail(nullptr, RTG_E_INVALID, "null mesh");
     // no context is involved: the mesh is immutable after creation and the copies below are blocking (errors are
     // reported through rtg_last_error(NULL))
@@ -966,15 +1003,19 @@ int rtg_mesh_read_bvh(const rtg_mesh *mesh, rtg_bvh_node *nodes, rtg_tri *leaves
             for (size_t i = 0; i < nl; i++) leaf_source[i] = (uint32_t)i;
     }
     return RTG_OK;
+} catch (...) {
+    return api_caught(nullptr, "rtg_mesh_read_bvh");
 }
 
-int rtg_mesh_bounds(const rtg_mesh *mesh, double out[6]) {
+int rtg_mesh_bounds(const rtg_mesh *mesh, double out[6]) try {
     if (!mesh || !out) return fail(nullptr, RTG_E_INVALID, "null argument");
     std::memcpy(out, mesh->bounds, sizeof(mesh->bounds));
     return RTG_OK;
+} catch (...) {
+    return api_caught(nullptr, "rtg_mesh_bounds");
 }
 
-int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) {
+int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) try {
     if (!ctx) return fail(nullptr, RTG_E_INVALID, "null ctx");
     if (!desc || !out) return fail(ctx, RTG_E_INVALID, "rtg_scene_create: null argument");
     *out = nullptr;
@@ -1078,6 +1119,8 @@ int rtg_scene_create(rtg_ctx *ctx, const rtg_scene_desc *desc, rtg_scene **out) 
     }
     *out = s;
     return RTG_OK;
+} catch (...) {
+    return api_caught(ctx, "rtg_scene_create");
 }
 
 void rtg_scene_destroy(rtg_scene *s) {
@@ -1089,7 +1132,7 @@ void rtg_scene_destroy(rtg_scene *s) {
 }
 
 int rtg_render_primary(rtg_scene *scene, const rtg_view *view, uint32_t width, uint32_t height, rtg_rect tile,
-                       rtg_hit *out_hits, rtg_point *out_points, rtg_ray_counters *out_counters) {
+                       rtg_hit *out_hits, rtg_point *out_points, rtg_ray_counters *out_counters) try {
     int rc = check_scene_call(scene);
     if (rc != RTG_OK) return rc;
     rtg_ctx *ctx = scene->ctx;
@@ -1129,10 +1172,12 @@ int rtg_render_primary(rtg_scene *scene, const rtg_view *view, uint32_t width, u
     if ((rc = out_finish(ctx, oc)) != RTG_OK) return rc;
     if (oh.staged || op.staged || oc.staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTG_OK;
+} catch (...) {
+    return api_caught(scene ? scene->ctx : nullptr, "rtg_render_primary");
 }
 
 int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *out_hits, rtg_point *out_points,
-              rtg_ray_counters *out_counters) {
+              rtg_ray_counters *out_counters) try {
     int rc = check_scene_call(scene);
     if (rc != RTG_OK) return rc;
     rtg_ctx *ctx = scene->ctx;
@@ -1198,10 +1243,12 @@ int rtg_trace(rtg_scene *scene, const double *rays6, uint64_t n_rays, rtg_hit *o
     if ((rc = out_finish(ctx, oc)) != RTG_OK) return rc;
     if (oh.staged || op.staged || oc.staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTG_OK;
+} catch (...) {
+    return api_caught(scene ? scene->ctx : nullptr, "rtg_trace");
 }
 
 int rtg_trace_paths(rtg_scene *scene, const double *rays6, uint64_t n_rays, uint32_t max_depth, rtg_path *out_paths,
-                    uint64_t capacity, uint64_t *n_paths) {
+                    uint64_t capacity, uint64_t *n_paths) try {
     int rc = check_scene_call(scene);
     if (rc != RTG_OK) return rc;
     rtg_ctx *ctx = scene->ctx;
@@ -1316,6 +1363,8 @@ int rtg_trace_paths(rtg_scene *scene, const double *rays6, uint64_t n_rays, uint
     if ((rc = out_finish(ctx, op)) != RTG_OK) return rc;
     if (op.staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTG_OK;
+} catch (...) {
+    return api_caught(scene ? scene->ctx : nullptr, "rtg_trace_paths");
 }
 
 namespace {
@@ -1463,7 +1512,7 @@ int api_shade_points(rtg_scene *scene, const rtg_light *d_lights, uint32_t n_lig
 } // extern "C++"
 
 int rtg_shade_direct(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const rtg_point *points,
-                     uint64_t n_points, double *rgb_out, uint8_t *rgba8_out) {
+                     uint64_t n_points, double *rgb_out, uint8_t *rgba8_out) try {
     int rc = check_scene_call(scene);
     if (rc != RTG_OK) return rc;
     rtg_ctx *ctx = scene->ctx;
@@ -1494,11 +1543,13 @@ int rtg_shade_direct(rtg_scene *scene, const rtg_light *lights, uint32_t n_light
     if ((rc = out_finish(ctx, o8)) != RTG_OK) return rc;
     if (orgb.staged || o8.staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTG_OK;
+} catch (...) {
+    return api_caught(scene ? scene->ctx : nullptr, "rtg_shade_direct");
 }
 
 int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *lights, uint32_t n_lights,
                      uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth, double *out_rgb,
-                     uint8_t *out_rgba8, rtg_hit *out_hits) {
+                     uint8_t *out_rgba8, rtg_hit *out_hits) try {
     int rc = check_scene_call(scene);
     if (rc != RTG_OK) return rc;
     rtg_ctx *ctx = scene->ctx;
@@ -1603,6 +1654,8 @@ int rtg_render_frame(rtg_scene *scene, const rtg_view *view, const rtg_light *li
     if ((rc = out_finish(ctx, oh)) != RTG_OK) return rc;
     if (orgb.staged || o8.staged || oh.staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTG_OK;
+} catch (...) {
+    return api_caught(scene ? scene->ctx : nullptr, "rtg_render_frame");
 }
 
 } // extern "C"

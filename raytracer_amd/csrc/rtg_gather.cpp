@@ -88,7 +88,7 @@ static_assert(RTG_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id blob is RCCL's 
 
 extern "C" {
 
-int rtg_comm_unique_id(uint8_t id[RTG_COMM_ID_BYTES]) {
+int rtg_comm_unique_id(uint8_t id[RTG_COMM_ID_BYTES]) try {
     if (!id) return api_fail(nullptr, RTG_E_INVALID, "rtg_comm_unique_id: id is null");
     const Rccl &r = rccl();
     if (!r.handle) return api_fail(nullptr, RTG_E_UNSUPPORTED, "rtg_comm_unique_id: %s", r.error.c_str());
@@ -97,9 +97,11 @@ int rtg_comm_unique_id(uint8_t id[RTG_COMM_ID_BYTES]) {
     if (e != ncclSuccess) return api_fail(nullptr, RTG_E_HIP, "ncclGetUniqueId: %s", r.GetErrorString(e));
     std::memcpy(id, u.internal, RTG_COMM_ID_BYTES);
     return RTG_OK;
+} catch (...) {
+    return rtg::api_caught(nullptr, "rtg_comm_unique_id");
 }
 
-int rtg_comm_create(rtg_ctx *ctx, const uint8_t id[RTG_COMM_ID_BYTES], int n_ranks, int rank, rtg_comm **out) {
+int rtg_comm_create(rtg_ctx *ctx, const uint8_t id[RTG_COMM_ID_BYTES], int n_ranks, int rank, rtg_comm **out) try {
     if (!ctx) return api_fail(nullptr, RTG_E_INVALID, "null ctx");
     if (!out) return api_fail(ctx, RTG_E_INVALID, "rtg_comm_create: out is null");
     *out = nullptr;
@@ -133,9 +135,11 @@ int rtg_comm_create(rtg_ctx *ctx, const uint8_t id[RTG_COMM_ID_BYTES], int n_ran
     }
     *out = c;
     return RTG_OK;
+} catch (...) {
+    return rtg::api_caught(ctx, "rtg_comm_create");
 }
 
-int rtg_comm_adopt(rtg_ctx *ctx, void *nccl_comm, int n_ranks, int rank, rtg_comm **out) {
+int rtg_comm_adopt(rtg_ctx *ctx, void *nccl_comm, int n_ranks, int rank, rtg_comm **out) try {
     if (!ctx) return api_fail(nullptr, RTG_E_INVALID, "null ctx");
     if (!out) return api_fail(ctx, RTG_E_INVALID, "rtg_comm_adopt: out is null");
     *out = nullptr;
@@ -154,6 +158,8 @@ int rtg_comm_adopt(rtg_ctx *ctx, void *nccl_comm, int n_ranks, int rank, rtg_com
     c->owned = false;
     *out = c;
     return RTG_OK;
+} catch (...) {
+    return rtg::api_caught(ctx, "rtg_comm_adopt");
 }
 
 void rtg_comm_destroy(rtg_comm *comm) {
@@ -166,7 +172,7 @@ void rtg_comm_destroy(rtg_comm *comm) {
 }
 
 int rtg_gather_tiles(rtg_comm *comm, int root, const void *send, void *recv, const rtg_piece *pieces,
-                     uint32_t n_pieces, void *hip_stream) {
+                     uint32_t n_pieces, void *hip_stream) try {
     if (!comm || !comm->ctx) return api_fail(nullptr, RTG_E_INVALID, "null communicator");
     rtg_ctx *ctx = comm->ctx;
     if (root < 0 || root >= comm->n_ranks) return api_fail(ctx, RTG_E_INVALID, "rtg_gather_tiles: root %d of %d ranks", root, comm->n_ranks);
@@ -221,6 +227,8 @@ int rtg_gather_tiles(rtg_comm *comm, int root, const void *send, void *recv, con
     if (first != ncclSuccess) return api_fail(ctx, RTG_E_HIP, "rtg_gather_tiles: piece %u: %s", bad, r.GetErrorString(first));
     if (e != ncclSuccess) return api_fail(ctx, RTG_E_HIP, "ncclGroupEnd: %s", r.GetErrorString(e));
     return RTG_OK;
+} catch (...) {
+    return rtg::api_caught(comm ? comm->ctx : nullptr, "rtg_gather_tiles");
 }
 
 } // extern "C"

@@ -3,8 +3,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstddef>
 #include <map>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -62,6 +65,12 @@ struct rtg_scene {
 namespace rtg {
 // Records `code`'s message on the context (or, without one, for rtg_last_error(NULL) on this thread); returns code.
 int api_fail(rtg_ctx *ctx, int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+// For the handler of an entry point's function-try-block: turns the exception in flight into a code and a message
+// (std::bad_alloc -> RTG_E_NOMEM).  Nothing may unwind through the C ABI: the host on the other side is not C++.
+int api_caught(rtg_ctx *ctx, const char *function) noexcept;
+// Runs f(begin, end) over [0, n) split into up to 16 ranges, each on its own host thread when threads can be had
+// (inline otherwise); returns after all ranges are done.  f must not throw.
+template <class F> void api_parallel_ranges(size_t n, size_t min_per_thread, F f);
 // True when `p` can be dereferenced by a kernel on the current device.
 bool api_is_device_pointer(const void *p);
 // A named device buffer of the context, grown on demand and kept for the next call.
@@ -77,4 +86,28 @@ int api_trace_device(rtg_scene *scene, const double *d_rays6, uint64_t n, rtg_hi
 // map's term `d_indirect`, 3 doubles per point or null, added first); asynchronous on the context's stream.
 int api_shade_points(rtg_scene *scene, const rtg_light *d_lights, uint32_t n_lights, const rtg_point *d_points, uint64_t n,
                      const double *d_indirect, double *d_rgb);
+
+template <class F> void api_parallel_ranges(size_t n, size_t min_per_thread, F f) {
+    unsigned t = std::thread::hardware_concurrency();
+    if (t > 16) t = 16;
+    if (min_per_thread && n / min_per_thread < t) t = (unsigned)(n / min_per_thread);
+    if (t < 2) {
+        f((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    size_t done = 0;                        // ranges [0, done) have a thread
+    try {
+        pool.reserve(t - 1);
+        for (unsigned w = 0; w + 1 < t; w++) {
+            const size_t b = n / t * w + std::min<size_t>(w, n % t), e = n / t * (w + 1) + std::min<size_t>(w + 1, n % t);
+            pool.emplace_back([=]() { f(b, e); });
+            done = e;
+        }
+    } catch (...) {
+        // no more threads to be had: the rest runs here
+    }
+    f(done, n);
+    for (auto &th : pool) th.join();
+}
 } // namespace rtg

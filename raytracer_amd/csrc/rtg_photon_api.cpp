@@ -11,6 +11,7 @@
 #include <cstddef>
 #include <limits>
 #include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -100,10 +101,17 @@ Box kd_build(HostKdNode *tree, size_t len, int fork) {
                      [axis](const HostKdNode &a, const HostKdNode &b) { return a.pos[axis] < b.pos[axis]; });
     tree[center].axis = (uint32_t)axis;
     Box left, right;
+    std::thread half;
     if (fork > 0 && len >= (size_t)1 << 16) {
-        std::thread t([&]() { left = kd_build(tree, center, fork - 1); });
+        try {
+            half = std::thread([&]() { left = kd_build(tree, center, fork - 1); });
+        } catch (const std::system_error &) {
+            // no thread to be had: both halves run here
+        }
+    }
+    if (half.joinable()) {
         right = kd_build(tree + center + 1, len - center - 1, fork - 1);
-        t.join();
+        half.join();
     } else {
         left = kd_build(tree, center, 0);
         right = kd_build(tree + center + 1, len - center - 1, 0);
@@ -206,7 +214,7 @@ extern "C" {
 
 int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const double *dirs2,
                      uint64_t count_per_light, uint32_t max_depth, rtg_photon *out_photons, uint64_t capacity,
-                     uint64_t *n_photons) {
+                     uint64_t *n_photons) try {
     int rc = api_bind_scene(scene);
     if (rc != RTG_OK) return rc;
     rtg_ctx *ctx = scene->ctx;
@@ -225,20 +233,20 @@ int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_light
     if ((rc = api_input(ctx, "photon_lights", lights, (size_t)n_lights * sizeof(rtg_light), &d_lights)) != RTG_OK) return rc;
     const uint64_t batch = 1ull << 19;                       // rays per rtg_trace_paths call (1.1 GB of path records at depth 4)
     const uint64_t per_ray = (1ull << max_depth) - 1;        // paths a ray can have
-    std::vector<double> rays;
-    uint64_t total = 0;
-    for (uint64_t first = 0; first < n_rays; first += batch) {
-        const uint64_t m = std::min(batch, n_rays - first);
-        rays.resize((size_t)m * 6);
-        // ZenithY::into_normal (src/geo/sphere.rs:29-34); Ray::new(light.sphere.orig(), ..) (renderer.rs:123): two libm
-        // calls and a square root per direction, spread over the host's cores
-        auto make_rays = [&](uint64_t begin, uint64_t end) {
-            for (uint64_t i = begin; i < end; i++) {
+    // ZenithY::into_normal (src/geo/sphere.rs:29-34); Ray::new(light.sphere.orig(), ..) (renderer.rs:123): two libm
+    // calls and a square root per direction, spread over the host's cores; the next batch's rays are made while the
+    // GPU traces this one
+    std::vector<double> rays[2];
+    rays[0].resize((size_t)std::min(batch, n_rays) * 6);
+    if (n_rays > batch) rays[1].resize((size_t)batch * 6);
+    auto make_batch = [&](uint64_t first, double *dst) {
+        api_parallel_ranges((size_t)std::min(batch, n_rays - first), 4096, [=](size_t begin, size_t end) {
+            for (size_t i = begin; i < end; i++) {
                 const uint64_t r = first + i;
                 const rtg_light &light = lights[r / count_per_light];
                 const double zenith = dirs2[r * 2], y = dirs2[r * 2 + 1];
                 const double radius = std::sqrt(1.0 - y * y);
-                double *w = &rays[(size_t)i * 6];
+                double *w = dst + i * 6;
                 w[0] = light.position[0];
                 w[1] = light.position[1];
                 w[2] = light.position[2];
@@ -246,22 +254,33 @@ int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_light
                 w[4] = y;
                 w[5] = libm_sin(zenith) * radius;
             }
-        };
-        {
-            unsigned n_threads = std::thread::hardware_concurrency();
-            n_threads = n_threads == 0 ? 1u : (n_threads > 16u ? 16u : n_threads);
-            if (m < 4096) n_threads = 1;
-            std::vector<std::thread> pool;
-            const uint64_t per = (m + n_threads - 1) / n_threads;
-            for (unsigned t = 1; t < n_threads; t++)
-                if (t * per < m) pool.emplace_back(make_rays, t * per, std::min(m, (t + 1) * per));
-            make_rays(0, std::min(m, per));
-            for (auto &th : pool) th.join();
+        });
+    };
+    struct Joined {
+        std::thread thread;
+        ~Joined() {
+            if (thread.joinable()) thread.join();
+        }
+    };
+    make_batch(0, rays[0].data());
+    uint64_t total = 0;
+    for (uint64_t first = 0, b = 0; first < n_rays; first += batch, b++) {
+        const uint64_t m = std::min(batch, n_rays - first);
+        const double *batch_rays = rays[b & 1].data();
+        Joined ahead;                                        // joined at the end of the iteration, however it ends
+        if (first + batch < n_rays) {
+            double *dst = rays[(b + 1) & 1].data();
+            const uint64_t next_first = first + batch;
+            try {
+                ahead.thread = std::thread([&make_batch, next_first, dst]() { make_batch(next_first, dst); });
+            } catch (const std::system_error &) {
+                make_batch(next_first, dst);
+            }
         }
         void *d_paths = nullptr;
         if ((rc = api_scratch(ctx, "photon_paths", (size_t)(m * per_ray) * sizeof(rtg_path), &d_paths)) != RTG_OK) return rc;
         uint64_t n_paths = 0;
-        if ((rc = rtg_trace_paths(scene, rays.data(), m, max_depth, (rtg_path *)d_paths, m * per_ray, &n_paths)) != RTG_OK) return rc;
+        if ((rc = rtg_trace_paths(scene, batch_rays, m, max_depth, (rtg_path *)d_paths, m * per_ray, &n_paths)) != RTG_OK) return rc;
         if (n_paths == 0) continue;
         void *flags = nullptr, *offsets = nullptr, *temp = nullptr, *d_out = nullptr;
         const void *d_dirs = nullptr;
@@ -292,9 +311,11 @@ int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_light
         return api_fail(ctx, RTG_E_LIMIT, "rtg_photons_emit: %llu photons, room for %llu", (unsigned long long)total,
                         (unsigned long long)capacity);
     return RTG_OK;
+} catch (...) {
+    return api_caught(scene ? scene->ctx : nullptr, "rtg_photons_emit");
 }
 
-int rtg_photon_map_create(rtg_ctx *ctx, const rtg_photon *photons, uint64_t n_photons, rtg_photon_map **out) {
+int rtg_photon_map_create(rtg_ctx *ctx, const rtg_photon *photons, uint64_t n_photons, rtg_photon_map **out) try {
     if (!ctx) return api_fail(nullptr, RTG_E_INVALID, "null ctx");
     if (!out) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_create: out is null");
     *out = nullptr;
@@ -341,6 +362,8 @@ int rtg_photon_map_create(rtg_ctx *ctx, const rtg_photon *photons, uint64_t n_ph
     }
     *out = m;
     return RTG_OK;
+} catch (...) {
+    return api_caught(ctx, "rtg_photon_map_create");
 }
 
 void rtg_photon_map_destroy(rtg_photon_map *map) {
@@ -352,7 +375,7 @@ void rtg_photon_map_destroy(rtg_photon_map *map) {
 }
 
 int rtg_photon_map_nearest(rtg_photon_map *map, const double *queries3, uint64_t n_queries, uint32_t k, uint32_t *out_index,
-                           double *out_distance) {
+                           double *out_distance) try {
     int rc = check_map_call(map);
     if (rc != RTG_OK) return rc;
     rtg_ctx *ctx = map->ctx;
@@ -387,10 +410,12 @@ int rtg_photon_map_nearest(rtg_photon_map *map, const double *queries3, uint64_t
     }
     if (staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTG_OK;
+} catch (...) {
+    return api_caught(map ? map->ctx : nullptr, "rtg_photon_map_nearest");
 }
 
 int rtg_indirect_irrad(rtg_scene *scene, rtg_photon_map *map, const rtg_point *points, uint64_t n_points, uint32_t photon_samples,
-                       uint32_t newton_steps, double newton_epsilon, double *rgb_out) {
+                       uint32_t newton_steps, double newton_epsilon, double *rgb_out) try {
     int rc = api_bind_scene(scene);
     if (rc != RTG_OK) return rc;
     rtg_ctx *ctx = scene->ctx;
@@ -410,12 +435,14 @@ int rtg_indirect_irrad(rtg_scene *scene, rtg_photon_map *map, const rtg_point *p
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return RTG_OK;
+} catch (...) {
+    return api_caught(scene ? scene->ctx : nullptr, "rtg_indirect_irrad");
 }
 
 int rtg_render_frame_photons(rtg_scene *scene, const rtg_view *view, const rtg_light *lights, uint32_t n_lights,
                              rtg_photon_map *map, uint32_t photon_samples, uint32_t newton_steps, double newton_epsilon,
                              uint32_t width, uint32_t height, rtg_rect tile, uint32_t max_depth, double *out_rgb,
-                             uint8_t *out_rgba8) {
+                             uint8_t *out_rgba8) try {
     int rc = api_bind_scene(scene);
     if (rc != RTG_OK) return rc;
     rtg_ctx *ctx = scene->ctx;
@@ -476,6 +503,8 @@ int rtg_render_frame_photons(rtg_scene *scene, const rtg_view *view, const rtg_l
     }
     if (staged) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTG_OK;
+} catch (...) {
+    return api_caught(scene ? scene->ctx : nullptr, "rtg_render_frame_photons");
 }
 
 } // extern "C"

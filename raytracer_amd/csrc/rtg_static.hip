@@ -52,7 +52,7 @@ hipError_t static_scratch_init(int device) {
 } // namespace rtg
 
 extern "C" int rtg_render_primary_static(rtg_scene *scene, const rtg_view *view, uint32_t width, uint32_t height,
-                                         rtg_rect tile, rtg_hit *out_hits) {
+                                         rtg_rect tile, rtg_hit *out_hits) try {
     using namespace rtg;
     if (!scene || !scene->ctx) return api_fail(nullptr, RTG_E_INVALID, "null scene");
     rtg_ctx *ctx = scene->ctx;
@@ -97,4 +97,6 @@ extern "C" int rtg_render_primary_static(rtg_scene *scene, const rtg_view *view,
         return api_fail(ctx, RTG_E_HIP, "rtg_render_primary_static: launch: %s", hipGetErrorString(e));
     }
     return RTG_OK;
+} catch (...) {
+    return rtg::api_caught(scene ? scene->ctx : nullptr, "rtg_render_primary_static");
 }
