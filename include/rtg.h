@@ -397,8 +397,17 @@ int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_light
                      uint64_t *n_photons);
 
 /* `KdTree::new(photons)` (src/tree/kd_tree.rs:74-95): a balanced k-d tree over the photons' positions, kept on the
- * GPU together with the photon records.  `photons` is host memory and is copied. */
+ * GPU together with the photon records.  `photons` is host or device memory and is copied; the tree is built on
+ * the GPU (the reference's selection is unstable, so which of several photons with equal coordinates becomes a
+ * range's root is as unspecified here as there).  A NaN position is refused (RTG_E_INVALID), as the reference's
+ * `NotNan` keys are. */
 int rtg_photon_map_create(rtg_ctx *ctx, const rtg_photon *photons, uint64_t n_photons, rtg_photon_map **out);
+/* The photon pass and `KdTree::new` in one call, `self.photons = KdTree::new(photons)` of `Renderer::render`
+ * (src/render/renderer.rs:116-140): rtg_photons_emit followed by rtg_photon_map_create, with the photon records
+ * never leaving the GPU (a map's photon indices, as rtg_photon_map_nearest reports them, count the records in the
+ * order rtg_photons_emit would have written them).  *n_photons (may be NULL) receives the number of photons. */
+int rtg_photon_map_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const double *dirs2,
+                        uint64_t count_per_light, uint32_t max_depth, rtg_photon_map **out, uint64_t *n_photons);
 void rtg_photon_map_destroy(rtg_photon_map *map);
 
 /* `KdTree::nearest(&p, k)` (src/tree/kd_tree.rs:115-154) for a batch of query points: out_index[q * k + j] is the

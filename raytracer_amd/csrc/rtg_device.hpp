@@ -874,4 +874,14 @@ __device__ __forceinline__ uint8_t pq8(double c) {
     return (uint8_t)__builtin_floor(255.0 * e + 0.5);
 }
 
+// One entry of the k-d tree.  The tree is implicit in the array (tree/seq_tree.rs:36-49): the root of a range is
+// its element at len / 2, the two subtrees are the ranges left and right of it.
+struct alignas(16) KdNode {
+    double pos[3];
+    double lo[3], hi[3];      // bounds of the subtree (KdEntry::bounds)
+    uint32_t value;           // index of the photon in the caller's order
+    uint32_t axis;
+};
+static_assert(sizeof(KdNode) == 80, "k-d node must be 5 x 16 B");
+
 } // namespace rtg

@@ -126,10 +126,14 @@ hipError_t launch_ray_sort(hipStream_t stream, const double *rays6, uint64_t n, 
 hipError_t launch_ray_unsort(hipStream_t stream, const rtg_hit *hits, const rtg_ray_counters *counters, const uint32_t *perm,
                              uint64_t n, rtg_hit *out_hits, rtg_ray_counters *out_counters);
 
-// The photon map (rtg_photon.hip).  `nodes` is the k-d tree as 80-byte records in implicit-median order (written by
-// the host build in rtg_photon_api.cpp); k <= 16.
+// The photon map (rtg_photon.hip).  `nodes` is the k-d tree as 80-byte records in implicit-median order; k <= 16.
 hipError_t launch_kd_nearest(hipStream_t stream, const void *nodes, uint32_t n_nodes, const double *queries3,
                              uint64_t n_queries, uint32_t k, uint32_t *out_index, double *out_distance);
+// KdTree::new on the device (rtg_kdtree.hip): `nodes` receives n 80-byte records in implicit-median order.  `scratch`
+// holds kd_build_scratch_bytes(n) bytes; *summary points at two words inside it, valid once the stream has drained:
+// the longest photon path (capped at 3) and the index of the first photon with a NaN coordinate (or 0xFFFFFFFF).
+size_t kd_build_scratch_bytes(uint32_t n);
+hipError_t build_kd_device(hipStream_t stream, const rtg_photon *photons, uint32_t n, void *scratch, void *nodes, uint32_t **summary);
 // Photons of one batch of path records: flags + exclusive scan (offsets[i] = photons before path i) + records
 // written at out[offsets[i]] while that is below `room`.
 size_t photon_scan_temp_bytes(uint32_t n);

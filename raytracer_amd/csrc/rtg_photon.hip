@@ -303,16 +303,6 @@ __device__ __forceinline__ const DevMaterial &material_of(const DevObject &o, co
 }
 
 // ---- nearest photons -----------------------------------------------------------------------------------
-// One entry of the k-d tree.  The tree is implicit in the array (tree/seq_tree.rs:36-49): the root of a range is
-// its element at len / 2, the two subtrees are the ranges left and right of it.
-struct alignas(16) KdNode {
-    double pos[3];
-    double lo[3], hi[3];      // bounds of the subtree (KdEntry::bounds)
-    uint32_t value;           // index of the photon in the caller's order
-    uint32_t axis;
-};
-static_assert(sizeof(KdNode) == 80, "k-d node must be 5 x 16 B");
-
 __device__ __forceinline__ bool rc_less(double a, double b) { return real_cmp(a, b) < 0; }
 
 template <int K>

@@ -2,8 +2,8 @@
 // photons and the caustic term of a surface point (src/render/renderer.rs:116-138, 206-265; src/tree/kd_tree.rs).
 //
 // Host-side duties only.  The photon pass turns the caller's emission directions into rays with the host's libm
-// (as the reference does) and hands them to rtg_trace_paths in batches; the k-d tree is built here, on the host,
-// with the reference's own recipe (median split on the widest axis, implicit in the array order) and uploaded once.
+// (as the reference does) and hands them to rtg_trace_paths in batches; the k-d tree is built on the device
+// (rtg_kdtree.hip) from the records the caller hands over, host or device memory.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -45,89 +45,6 @@ namespace {
 // the pair into sincos() changes the last place of about one direction in a thousand (glibc).
 double (*volatile libm_sin)(double) = ::sin;
 double (*volatile libm_cos)(double) = ::cos;
-
-// One entry of the k-d tree as the kernel reads it (KdNode in rtg_photon.hip).
-struct alignas(16) HostKdNode {
-    double pos[3];
-    double lo[3], hi[3];
-    uint32_t value;
-    uint32_t axis;
-};
-static_assert(sizeof(HostKdNode) == 80, "k-d node must be 5 x 16 B");
-
-// f64::minimum / f64::maximum as Bounds::union uses them (src/geo/bounds.rs:28-33)
-double f_min(double a, double b) {
-    if (a != a) return a;
-    if (b != b) return b;
-    if (a < b) return a;
-    if (b < a) return b;
-    return std::signbit(a) ? a : b;
-}
-double f_max(double a, double b) {
-    if (a != a) return a;
-    if (b != b) return b;
-    if (a > b) return a;
-    if (b > a) return b;
-    return std::signbit(a) ? b : a;
-}
-struct Box {
-    double lo[3], hi[3];
-};
-Box box_empty() {
-    const double inf = std::numeric_limits<double>::infinity();
-    return Box{{inf, inf, inf}, {-inf, -inf, -inf}};
-}
-void box_add(Box &b, const Box &o) {
-    for (int i = 0; i < 3; i++) {
-        b.lo[i] = f_min(b.lo[i], o.lo[i]);
-        b.hi[i] = f_max(b.hi[i], o.hi[i]);
-    }
-}
-// KdTree::build_rec (src/tree/kd_tree.rs:79-95) over tree[0..len); subtrees large enough run on their own threads
-// down to `fork` levels.
-Box kd_build(HostKdNode *tree, size_t len, int fork) {
-    Box bounds = box_empty();
-    if (len == 0) return bounds;
-    for (size_t i = 0; i < len; i++)
-        for (int k = 0; k < 3; k++) {
-            bounds.lo[k] = f_min(bounds.lo[k], tree[i].pos[k]);
-            bounds.hi[k] = f_max(bounds.hi[k], tree[i].pos[k]);
-        }
-    int axis = 0;                           // max_by_key: the last of equal maxima
-    for (int i = 1; i < 3; i++)
-        if (!(bounds.hi[i] - bounds.lo[i] < bounds.hi[axis] - bounds.lo[axis])) axis = i;
-    const size_t center = len / 2;          // src/tree/seq_tree.rs:41
-    std::nth_element(tree, tree + center, tree + len,
-                     [axis](const HostKdNode &a, const HostKdNode &b) { return a.pos[axis] < b.pos[axis]; });
-    tree[center].axis = (uint32_t)axis;
-    Box left, right;
-    std::thread half;
-    if (fork > 0 && len >= (size_t)1 << 16) {
-        try {
-            half = std::thread([&]() { left = kd_build(tree, center, fork - 1); });
-        } catch (const std::system_error &) {
-            // no thread to be had: both halves run here
-        }
-    }
-    if (half.joinable()) {
-        right = kd_build(tree + center + 1, len - center - 1, fork - 1);
-        half.join();
-    } else {
-        left = kd_build(tree, center, 0);
-        right = kd_build(tree + center + 1, len - center - 1, 0);
-    }
-    Box b = box_empty();
-    box_add(b, left);
-    box_add(b, right);
-    Box self;
-    for (int k = 0; k < 3; k++) self.lo[k] = self.hi[k] = tree[center].pos[k];
-    box_add(b, self);
-    for (int k = 0; k < 3; k++) {
-        tree[center].lo[k] = b.lo[k];
-        tree[center].hi[k] = b.hi[k];
-    }
-    return b;
-}
 
 int check_map_call(rtg_photon_map *map) {
     if (!map || !map->ctx) return api_fail(nullptr, RTG_E_INVALID, "null photon map");
@@ -208,27 +125,39 @@ int indirect_device(rtg_scene *scene, rtg_photon_map *map, const rtg_point *d_po
     return RTG_OK;
 }
 
-} // namespace
+// Where the photons of a pass go: the caller's buffer (host or device) of `capacity` records, or a device buffer
+// held here that grows as the batches arrive.
+struct PhotonSink {
+    rtg_photon *user = nullptr;
+    uint64_t capacity = 0;
+    bool grow = false;
+    void *held = nullptr;
+    uint64_t held_capacity = 0;
+    ~PhotonSink() {
+        if (held) (void)hipFree(held);
+    }
+};
 
-extern "C" {
+int check_emit_args(rtg_ctx *ctx, const rtg_light *lights, uint32_t n_lights, const double *dirs2, uint64_t count_per_light,
+                    uint32_t max_depth) {
+    if (max_depth < 1 || max_depth > 4) return api_fail(ctx, RTG_E_INVALID, "photon pass: max_depth must be 1..4");
+    if ((uint64_t)n_lights * count_per_light == 0) return RTG_OK;
+    if (!lights || !dirs2) return api_fail(ctx, RTG_E_INVALID, "photon pass: lights / dirs2 is null");
+    if (api_is_device_pointer(lights) || api_is_device_pointer(dirs2))
+        return api_fail(ctx, RTG_E_INVALID, "photon pass: lights and dirs2 are host memory (the directions' sin / cos are taken on the host)");
+    if (count_per_light > (1ull << 40) || (uint64_t)n_lights * count_per_light > (1ull << 40))
+        return api_fail(ctx, RTG_E_LIMIT, "photon pass: too many directions");
+    return RTG_OK;
+}
 
-int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const double *dirs2,
-                     uint64_t count_per_light, uint32_t max_depth, rtg_photon *out_photons, uint64_t capacity,
-                     uint64_t *n_photons) try {
-    int rc = api_bind_scene(scene);
-    if (rc != RTG_OK) return rc;
+// renderer.rs:116-138 for checked arguments; *n_total receives the number of photons the pass makes.
+int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const double *dirs2, uint64_t count_per_light,
+                 uint32_t max_depth, PhotonSink &sink, uint64_t *n_total) {
     rtg_ctx *ctx = scene->ctx;
-    if (!n_photons) return api_fail(ctx, RTG_E_INVALID, "rtg_photons_emit: n_photons is null");
-    *n_photons = 0;
-    if (max_depth < 1 || max_depth > 4) return api_fail(ctx, RTG_E_INVALID, "rtg_photons_emit: max_depth must be 1..4");
+    int rc;
+    *n_total = 0;
     const uint64_t n_rays = (uint64_t)n_lights * count_per_light;
     if (n_rays == 0) return RTG_OK;
-    if (!lights || !dirs2) return api_fail(ctx, RTG_E_INVALID, "rtg_photons_emit: lights / dirs2 is null");
-    if (api_is_device_pointer(lights) || api_is_device_pointer(dirs2))
-        return api_fail(ctx, RTG_E_INVALID, "rtg_photons_emit: lights and dirs2 are host memory (the directions' sin / cos are taken on the host)");
-    if (capacity && !out_photons) return api_fail(ctx, RTG_E_INVALID, "rtg_photons_emit: out_photons is null");
-    if (count_per_light > (1ull << 40) || n_rays > (1ull << 40)) return api_fail(ctx, RTG_E_LIMIT, "rtg_photons_emit: too many directions");
-
     const void *d_lights = nullptr;
     if ((rc = api_input(ctx, "photon_lights", lights, (size_t)n_lights * sizeof(rtg_light), &d_lights)) != RTG_OK) return rc;
     const uint64_t batch = 1ull << 19;                       // rays per rtg_trace_paths call (1.1 GB of path records at depth 4)
@@ -289,7 +218,7 @@ int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_light
         if ((rc = api_scratch(ctx, "photon_offsets", (size_t)n_paths * sizeof(uint32_t), &offsets)) != RTG_OK) return rc;
         if ((rc = api_scratch(ctx, "photon_scan_temp", temp_bytes, &temp)) != RTG_OK) return rc;
         // a batch writes only what still fits the caller's room
-        const uint64_t room = capacity > total ? std::min<uint64_t>(capacity - total, n_paths) : 0;
+        const uint64_t room = sink.grow ? n_paths : (sink.capacity > total ? std::min<uint64_t>(sink.capacity - total, n_paths) : 0);
         if ((rc = api_scratch(ctx, "photon_out", (size_t)std::max<uint64_t>(room, 1) * sizeof(rtg_photon), &d_out)) != RTG_OK) return rc;
         if ((rc = api_input(ctx, "photon_dirs", dirs2 + first * 2, (size_t)m * 2 * sizeof(double), &d_dirs)) != RTG_OK) return rc;
         HIP_TRY(ctx, launch_photons_from_paths(ctx->stream, (const rtg_path *)d_paths, (uint32_t)n_paths, (const double *)d_dirs,
@@ -300,12 +229,99 @@ int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_light
         HIP_TRY(ctx, hipMemcpyAsync(&last[1], (const uint32_t *)flags + (n_paths - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const uint64_t made = (uint64_t)last[0] + last[1];
-        if (total + made <= capacity) {
-            if ((rc = copy_out(ctx, out_photons + total, d_out, (size_t)made * sizeof(rtg_photon))) != RTG_OK) return rc;
+        if (sink.grow) {
+            if (total + made > sink.held_capacity) {
+                const uint64_t want = std::max<uint64_t>({total + made, sink.held_capacity * 2, (uint64_t)1 << 16});
+                void *bigger = nullptr;
+                HIP_TRY(ctx, hipMalloc(&bigger, (size_t)want * sizeof(rtg_photon)));
+                hipError_t e = total ? hipMemcpyAsync(bigger, sink.held, (size_t)total * sizeof(rtg_photon), hipMemcpyDeviceToDevice, ctx->stream)
+                                     : hipSuccess;
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) {
+                    (void)hipFree(bigger);
+                    (void)hipGetLastError();
+                    return api_fail(ctx, RTG_E_HIP, "photon pass: %s", hipGetErrorString(e));
+                }
+                if (sink.held) (void)hipFree(sink.held);
+                sink.held = bigger;
+                sink.held_capacity = want;
+            }
+            HIP_TRY(ctx, hipMemcpyAsync((rtg_photon *)sink.held + total, d_out, (size_t)made * sizeof(rtg_photon), hipMemcpyDeviceToDevice,
+                                        ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the scratch is reused by the next batch
+        } else if (total + made <= sink.capacity) {
+            if ((rc = copy_out(ctx, sink.user + total, d_out, (size_t)made * sizeof(rtg_photon))) != RTG_OK) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the scratch is reused by the next batch
         }
         total += made;
     }
+    *n_total = total;
+    return RTG_OK;
+}
+
+// KdTree::new over `n` photon records already on the context's GPU; the records (hipMalloc'ed) belong to the map
+// from here on, or are freed when the call fails.
+int map_over(rtg_ctx *ctx, void *d_photons, uint64_t n_photons, rtg_photon_map **out) {
+    rtg_photon_map *m = new (std::nothrow) rtg_photon_map();
+    if (!m) {
+        if (d_photons) (void)hipFree(d_photons);
+        return api_fail(ctx, RTG_E_NOMEM, "out of host memory");
+    }
+    m->ctx = ctx;
+    m->device = ctx->device;
+    m->n = n_photons;
+    m->d_photons = d_photons;
+    if (n_photons == 0) {
+        *out = m;
+        return RTG_OK;
+    }
+    const uint32_t n = (uint32_t)n_photons;
+    void *scratch = nullptr;
+    int rc = api_scratch(ctx, "kd_build", kd_build_scratch_bytes(n), &scratch);
+    if (rc != RTG_OK) {
+        rtg_photon_map_destroy(m);
+        return rc;
+    }
+    uint32_t *d_summary = nullptr;
+    uint32_t summary[2] = {0, 0xFFFFFFFFu};
+    hipError_t e = hipMalloc(&m->d_nodes, (size_t)n * sizeof(KdNode));
+    if (e == hipSuccess) e = build_kd_device(ctx->stream, (const rtg_photon *)m->d_photons, n, scratch, m->d_nodes, &d_summary);
+    if (e == hipSuccess) e = hipMemcpyAsync(summary, d_summary, sizeof(summary), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rtg_photon_map_destroy(m);
+        return api_fail(ctx, e == hipErrorOutOfMemory ? RTG_E_NOMEM : RTG_E_HIP, "photon map: %s", hipGetErrorString(e));
+    }
+    if (summary[1] != 0xFFFFFFFFu) {
+        // the reference refuses NaN keys (NotNan::try_from(..).unwrap(), src/tree/kd_tree.rs:81-82)
+        rtg_photon_map_destroy(m);
+        return api_fail(ctx, RTG_E_INVALID, "photon map: photon %u has a NaN position", summary[1]);
+    }
+    m->max_bounces = summary[0];
+    *out = m;
+    return RTG_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const double *dirs2,
+                     uint64_t count_per_light, uint32_t max_depth, rtg_photon *out_photons, uint64_t capacity,
+                     uint64_t *n_photons) try {
+    int rc = api_bind_scene(scene);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = scene->ctx;
+    if (!n_photons) return api_fail(ctx, RTG_E_INVALID, "rtg_photons_emit: n_photons is null");
+    *n_photons = 0;
+    if ((rc = check_emit_args(ctx, lights, n_lights, dirs2, count_per_light, max_depth)) != RTG_OK) return rc;
+    if (capacity && !out_photons) return api_fail(ctx, RTG_E_INVALID, "rtg_photons_emit: out_photons is null");
+    PhotonSink sink;
+    sink.user = out_photons;
+    sink.capacity = capacity;
+    uint64_t total = 0;
+    if ((rc = emit_photons(scene, lights, n_lights, dirs2, count_per_light, max_depth, sink, &total)) != RTG_OK) return rc;
     *n_photons = total;
     if (total > capacity)
         return api_fail(ctx, RTG_E_LIMIT, "rtg_photons_emit: %llu photons, room for %llu", (unsigned long long)total,
@@ -321,49 +337,44 @@ int rtg_photon_map_create(rtg_ctx *ctx, const rtg_photon *photons, uint64_t n_ph
     *out = nullptr;
     if (n_photons && !photons) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_create: photons is null");
     if (n_photons >= (1ull << 31)) return api_fail(ctx, RTG_E_LIMIT, "rtg_photon_map_create: at most 2^31 - 1 photons");
-    if (api_is_device_pointer(photons)) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_create: photons is host memory");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    std::vector<HostKdNode> tree;
-    try {
-        tree.resize((size_t)n_photons);
-    } catch (const std::bad_alloc &) {
-        return api_fail(ctx, RTG_E_NOMEM, "out of host memory");
-    }
-    uint32_t max_bounces = 0;
-    for (uint64_t i = 0; i < n_photons; i++) {
-        HostKdNode &k = tree[(size_t)i];
-        for (int c = 0; c < 3; c++) {
-            k.pos[c] = photons[i].position[c];
-            // the reference refuses NaN keys (NotNan::try_from(..).unwrap(), src/tree/kd_tree.rs:81-82)
-            if (k.pos[c] != k.pos[c]) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_create: photon %llu has a NaN position", (unsigned long long)i);
-            k.lo[c] = k.hi[c] = std::numeric_limits<double>::quiet_NaN();
-        }
-        k.value = (uint32_t)i;
-        k.axis = 0;
-        max_bounces = std::max(max_bounces, std::min(photons[i].n_bounces, 3u));
-    }
-    kd_build(tree.data(), tree.size(), 3);
-    rtg_photon_map *m = new (std::nothrow) rtg_photon_map();
-    if (!m) return api_fail(ctx, RTG_E_NOMEM, "out of host memory");
-    m->ctx = ctx;
-    m->device = ctx->device;
-    m->n = n_photons;
-    m->max_bounces = max_bounces;
+    void *d_photons = nullptr;
     if (n_photons) {
-        hipError_t e = hipMalloc(&m->d_nodes, tree.size() * sizeof(HostKdNode));
-        if (e == hipSuccess) e = hipMalloc(&m->d_photons, (size_t)n_photons * sizeof(rtg_photon));
-        if (e == hipSuccess) e = hipMemcpy(m->d_nodes, tree.data(), tree.size() * sizeof(HostKdNode), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(m->d_photons, photons, (size_t)n_photons * sizeof(rtg_photon), hipMemcpyHostToDevice);
+        HIP_TRY(ctx, hipMalloc(&d_photons, (size_t)n_photons * sizeof(rtg_photon)));
+        hipError_t e = hipMemcpyAsync(d_photons, photons, (size_t)n_photons * sizeof(rtg_photon),
+                                      api_is_device_pointer(photons) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) {
+            (void)hipFree(d_photons);
             (void)hipGetLastError();
-            rtg_photon_map_destroy(m);
-            return api_fail(ctx, e == hipErrorOutOfMemory ? RTG_E_NOMEM : RTG_E_HIP, "rtg_photon_map_create: %s", hipGetErrorString(e));
+            return api_fail(ctx, RTG_E_HIP, "rtg_photon_map_create: %s", hipGetErrorString(e));
         }
     }
-    *out = m;
-    return RTG_OK;
+    return map_over(ctx, d_photons, n_photons, out);
 } catch (...) {
     return api_caught(ctx, "rtg_photon_map_create");
+}
+
+int rtg_photon_map_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const double *dirs2, uint64_t count_per_light,
+                        uint32_t max_depth, rtg_photon_map **out, uint64_t *n_photons) try {
+    int rc = api_bind_scene(scene);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = scene->ctx;
+    if (!out) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_emit: out is null");
+    *out = nullptr;
+    if (n_photons) *n_photons = 0;
+    if ((rc = check_emit_args(ctx, lights, n_lights, dirs2, count_per_light, max_depth)) != RTG_OK) return rc;
+    PhotonSink sink;
+    sink.grow = true;
+    uint64_t total = 0;
+    if ((rc = emit_photons(scene, lights, n_lights, dirs2, count_per_light, max_depth, sink, &total)) != RTG_OK) return rc;
+    if (total >= (1ull << 31)) return api_fail(ctx, RTG_E_LIMIT, "rtg_photon_map_emit: %llu photons, at most 2^31 - 1", (unsigned long long)total);
+    void *d_photons = total ? sink.held : nullptr;       // map_over owns the records from here on
+    if (total) sink.held = nullptr;
+    if ((rc = map_over(ctx, d_photons, total, out)) != RTG_OK) return rc;
+    if (n_photons) *n_photons = total;
+    return RTG_OK;
+} catch (...) {
+    return api_caught(scene ? scene->ctx : nullptr, "rtg_photon_map_emit");
 }
 
 void rtg_photon_map_destroy(rtg_photon_map *map) {

@@ -115,6 +115,30 @@ int rth_render_scene_builder(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32
     if (out_hits) std::memcpy(out_hits, r.hits().data(), r.hits().size() * sizeof(rtg_hit));
     return RTG_OK;
 }
+int rth_render_scene_builder_photons(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32_t height, uint32_t max_depth,
+                                     uint64_t photon_count, uint64_t seed, double *out_rgb, uint64_t *n_photons,
+                                     double seconds[3]) {
+    rt::SceneBuilder sb;
+    sb.time = time;
+    rt::Scene scene = sb.scene();
+    scene.size[0] = width;
+    scene.size[1] = height;
+    scene.photon_count = photon_count;
+    rt::Renderer r(ctx, std::move(scene));
+    r.max_depth = max_depth;
+    r.photon_pass = true;
+    r.seed = seed;
+    int rc = r.render();
+    if (n_photons) *n_photons = r.photons();
+    if (seconds) {
+        seconds[0] = r.seconds_directions();
+        seconds[1] = r.seconds_photons();
+        seconds[2] = r.seconds_pixels();
+    }
+    if (rc != RTG_OK) return rc;
+    if (out_rgb) std::memcpy(out_rgb, r.radiosity().data(), r.radiosity().size() * sizeof(double));
+    return RTG_OK;
+}
 uint64_t rth_to_hdr(const double *rgb, uint32_t width, uint32_t height, uint8_t *out, uint64_t cap) {
     std::vector<uint8_t> b = rt::to_hdr(rgb, width, height);
     if (out && cap >= b.size()) std::memcpy(out, b.data(), b.size());

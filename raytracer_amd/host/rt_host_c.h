@@ -44,6 +44,12 @@ void rth_scene_builder(uint64_t time, rtg_object objects[2], rtg_light lights[2]
  * and returns the radiosity (3 doubles per pixel) and primary hits. */
 int rth_render_scene_builder(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32_t height, uint32_t max_depth,
                              double *out_rgb, rtg_hit *out_hits);
+/* The same with the photon pass of Renderer::render (src/render/renderer.rs:116-140): `photon_count` Fibonacci
+ * directions per light from `seed` (the reference seeds from entropy), the photon map, and the pixel pass with the
+ * photon term.  seconds[3] (may be NULL): directions, photon pass + k-d tree, pixel pass. */
+int rth_render_scene_builder_photons(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32_t height, uint32_t max_depth,
+                                     uint64_t photon_count, uint64_t seed, double *out_rgb, uint64_t *n_photons,
+                                     double seconds[3]);
 /* Radiance .hdr bytes of an RGB double image; returns the byte count (call with out == NULL to size). */
 /* The three images of Renderer::images (image.hdr, image.pq.hdr, perf.hdr) of an RGB double frame rendered in
  * `seconds`, framed as the tar archive the reference's server returns (bin/server.rs:19-30); returns the byte count. */

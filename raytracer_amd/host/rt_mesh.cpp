@@ -2,6 +2,8 @@
 #include "rt_mesh.hpp"
 
 #include <cmath>
+#include <thread>
+#include <vector>
 
 namespace rt {
 namespace {
@@ -129,14 +131,38 @@ void fibonacci_zenith_y(uint64_t count, uint64_t seed, double *dirs2) {
     const double d = 2.0 * pi / phi;
     const double dydi = 2.0 / (n + d);
     const double dydj = dydi * d;
-    uint64_t s = seed;
-    auto uni = [&s]() { return (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0); };
-    for (uint64_t k = 0; k < count; k++) {
-        double i = (double)k + uni();
-        double j = uni();
-        dirs2[k * 2 + 0] = std::fmod(phi * i, 2.0 * pi);
-        dirs2[k * 2 + 1] = -1.0 + dydi * i + dydj * j;
+    // direction k takes draws 2k and 2k + 1 of the stream, whose state after m draws is seed + m * gamma: any range
+    // of directions can start on its own, so the host's cores share them
+    auto range = [=](uint64_t begin, uint64_t end) {
+        uint64_t s = seed + 2 * begin * 0x9E3779B97F4A7C15ull;
+        auto uni = [&s]() { return (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0); };
+        for (uint64_t k = begin; k < end; k++) {
+            double i = (double)k + uni();
+            double j = uni();
+            dirs2[k * 2 + 0] = std::fmod(phi * i, 2.0 * pi);
+            dirs2[k * 2 + 1] = -1.0 + dydi * i + dydj * j;
+        }
+    };
+    unsigned threads = std::thread::hardware_concurrency();
+    threads = threads > 16 ? 16 : threads;
+    if (threads < 2 || count < (1u << 16)) {
+        range(0, count);
+        return;
     }
+    std::vector<std::thread> pool;
+    uint64_t done = 0;
+    try {
+        pool.reserve(threads - 1);
+        for (unsigned t = 0; t + 1 < threads; t++) {
+            const uint64_t end = count / threads * (t + 1);
+            pool.emplace_back(range, done, end);
+            done = end;
+        }
+    } catch (...) {
+        // no more threads to be had: the rest runs here
+    }
+    range(done, count);
+    for (auto &th : pool) th.join();
 }
 
 uint64_t ray_sort_key(const double b[6], const double *ray6) {

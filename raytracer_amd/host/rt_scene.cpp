@@ -1,6 +1,8 @@
 // rt_scene.cpp -- see rt_scene.hpp.
 #include "rt_scene.hpp"
 
+#include "rt_mesh.hpp"
+
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -190,6 +192,7 @@ Scene SceneBuilder::scene() const {                            // lib.rs:109-120
 // ---- Renderer ---------------------------------------------------------------------
 Renderer::Renderer(rtg_ctx *ctx, Scene scene) : ctx_(ctx), scene_(std::move(scene)) {}
 Renderer::~Renderer() {
+    if (photon_map_) rtg_photon_map_destroy(photon_map_);
     if (gpu_scene_) rtg_scene_destroy(gpu_scene_);
 }
 const char *Renderer::error() const { return rtg_last_error(ctx_); }
@@ -213,10 +216,39 @@ int Renderer::render() {
     rgb_.assign((size_t)w * h * 3, 0.0);
     hits_.assign((size_t)w * h, rtg_hit{RTG_NONE, RTG_NONE, 0.0});
     rtg_view v = scene_.view.c();
+    auto since = [](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+    };
+    if (!photon_pass) {
+        auto t0 = std::chrono::steady_clock::now();
+        int rc = rtg_render_frame(gpu_scene_, &v, lights.data(), (uint32_t)lights.size(), w, h, rtg_rect{0, 0, w, h},
+                                  max_depth, rgb_.data(), nullptr, hits_.data());
+        seconds_ = since(t0);
+        return rc;
+    }
+    // renderer.rs:116-140: a Fibonacci sphere of directions per light, every path behind a specular bounce a photon,
+    // the photons in a k-d tree
     auto t0 = std::chrono::steady_clock::now();
-    int rc = rtg_render_frame(gpu_scene_, &v, lights.data(), (uint32_t)lights.size(), w, h, rtg_rect{0, 0, w, h},
-                              max_depth, rgb_.data(), nullptr, hits_.data());
-    seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<double> dirs(lights.size() * (size_t)scene_.photon_count * 2);
+    for (size_t l = 0; l < lights.size(); l++)
+        fibonacci_zenith_y(scene_.photon_count, seed + 0x9E3779B97F4A7C15ull * l, dirs.data() + l * (size_t)scene_.photon_count * 2);
+    seconds_dirs_ = since(t0);
+    t0 = std::chrono::steady_clock::now();
+    if (photon_map_) {
+        rtg_photon_map_destroy(photon_map_);
+        photon_map_ = nullptr;
+    }
+    int rc = rtg_photon_map_emit(gpu_scene_, lights.data(), (uint32_t)lights.size(), dirs.data(), scene_.photon_count, max_depth,
+                                 &photon_map_, &n_photons_);
+    seconds_photons_ = since(t0);
+    if (rc != RTG_OK) return rc;
+    // renderer.rs:141-153: the pixel pass
+    t0 = std::chrono::steady_clock::now();
+    rc = rtg_render_frame_photons(gpu_scene_, &v, lights.data(), (uint32_t)lights.size(), photon_map_, scene_.photon_samples,
+                                  scene_.newton_steps, scene_.newton_epsilon, w, h, rtg_rect{0, 0, w, h}, max_depth, rgb_.data(),
+                                  nullptr);
+    if (rc == RTG_OK) rc = rtg_render_primary(gpu_scene_, &v, w, h, rtg_rect{0, 0, w, h}, hits_.data(), nullptr, nullptr);
+    seconds_ = since(t0);
     return rc;
 }
 

@@ -87,8 +87,8 @@ struct Object {
     static Object model(const Transform &t, std::shared_ptr<GpuMesh> mesh, Material m);      // MeshObject::new
 };
 
-// render/renderer.rs:44-53.  The photon fields are carried for interface
-// parity; the GPU path renders the direct + specular terms only.
+// render/renderer.rs:44-53.  The photon fields take effect when the Renderer's
+// photon pass is switched on.
 struct Scene {
     uint32_t size[2] = {300, 300};
     View view;
@@ -118,12 +118,22 @@ class Renderer {
   public:
     Renderer(rtg_ctx *ctx, Scene scene);          // Renderer::new
     ~Renderer();
-    int render();                                 // Renderer::render: the pixel pass on the GPU
+    // Renderer::render on the GPU: the pixel pass, after the photon pass (renderer.rs:116-140) when `photon_pass`
+    // is set, in which case every pixel carries the photon map's term as well.
+    int render();
     std::map<std::string, std::vector<uint8_t>> images() const;   // image.hdr, image.pq.hdr, perf.hdr
     const std::vector<double> &radiosity() const { return rgb_; }
     const std::vector<rtg_hit> &hits() const { return hits_; }
     const char *error() const;
     uint32_t max_depth = 4;                       // renderer.rs:312
+    bool photon_pass = false;
+    uint64_t seed = 1;                            // stands for the entropy-seeded generator of renderer.rs:112
+    uint64_t photons() const { return n_photons_; }
+    // wall time of the last render's parts: directions (the caller's side in the reference), photon pass + k-d
+    // tree, pixel pass
+    double seconds_directions() const { return seconds_dirs_; }
+    double seconds_photons() const { return seconds_photons_; }
+    double seconds_pixels() const { return seconds_; }
 
   private:
     rtg_ctx *ctx_;
@@ -131,7 +141,9 @@ class Renderer {
     rtg_scene *gpu_scene_ = nullptr;
     std::vector<double> rgb_;
     std::vector<rtg_hit> hits_;
-    double seconds_ = 0;
+    double seconds_ = 0, seconds_dirs_ = 0, seconds_photons_ = 0;
+    rtg_photon_map *photon_map_ = nullptr;
+    uint64_t n_photons_ = 0;
 };
 
 std::shared_ptr<GpuMesh> upload_mesh(rtg_ctx *ctx, Bvh bvh);

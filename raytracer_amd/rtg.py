@@ -149,6 +149,7 @@ _sig(lib.rtg_render_frame, C.c_int, _vp, C.POINTER(View), _vp, C.c_uint32, C.c_u
      C.c_uint32, _vp, _vp, _vp)
 _sig(lib.rtg_photons_emit, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64))
 _sig(lib.rtg_photon_map_create, C.c_int, _vp, _vp, C.c_uint64, C.POINTER(_vp))
+_sig(lib.rtg_photon_map_emit, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.POINTER(_vp), C.POINTER(C.c_uint64))
 _sig(lib.rtg_photon_map_destroy, None, _vp)
 _sig(lib.rtg_photon_map_nearest, C.c_int, _vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp)
 _sig(lib.rtg_render_frame_photons, C.c_int, _vp, C.POINTER(View), _vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_double,
@@ -179,6 +180,8 @@ _sig(host.rth_patch_terrain, None, C.c_uint32, C.c_uint32, C.c_uint64, C.c_doubl
 _sig(host.rth_transform_build, None, C.c_double, C.POINTER(C.c_double), C.POINTER(Transform))
 _sig(host.rth_scene_builder, None, C.c_uint64, C.POINTER(Object), C.POINTER(Light), C.POINTER(View))
 _sig(host.rth_render_scene_builder, C.c_int, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp)
+_sig(host.rth_render_scene_builder_photons, C.c_int, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _vp,
+     C.POINTER(C.c_uint64), _vp)
 _sig(host.rth_to_hdr, C.c_uint64, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64)
 _sig(host.rth_images_tar, C.c_uint64, _vp, C.c_uint32, C.c_uint32, C.c_double, _vp, C.c_uint64)
 
@@ -536,12 +539,23 @@ class PhotonMap:
     """KdTree<Photon> on the GPU: nearest photons of a batch of points; handed to Scene.indirect_irrad."""
     _h = None
 
-    def __init__(self, ctx, photons):
-        self.photons = np.ascontiguousarray(photons, dtype=PHOTON_DTYPE)
+    def __init__(self, ctx, photons, n=None, _handle=None):
+        """photons: PHOTON_DTYPE records, or (with n) the address of n records in host or device memory."""
+        if _handle is not None:            # made by Scene.photon_map
+            self.photons = None
+            self._h, self.ctx, self.n = _handle, ctx, n
+            ctx._scenes.add(self)
+            return
         h = _vp()
-        ctx._check(lib.rtg_photon_map_create(ctx._h, _ptr(self.photons) if self.photons.shape[0] else None,
-                                             self.photons.shape[0], C.byref(h)))
-        self._h, self.ctx = h, ctx
+        if n is None:
+            self.photons = np.ascontiguousarray(photons, dtype=PHOTON_DTYPE)
+            n = self.photons.shape[0]
+            ptr = _ptr(self.photons) if n else None
+        else:
+            self.photons = None
+            ptr = _ptr(photons) if n else None
+        ctx._check(lib.rtg_photon_map_create(ctx._h, ptr, n, C.byref(h)))
+        self._h, self.ctx, self.n = h, ctx, n
         ctx._scenes.add(self)              # closed before the context, like a scene
 
     def nearest(self, queries3, k):
@@ -785,6 +799,24 @@ class Scene:
                                              _ptr(out) if capacity else None, capacity, C.byref(count)))
         return out[:count.value].copy()
 
+    def photon_map(self, lights, dirs2, max_depth=4):
+        """The photon pass and KdTree::new in one call, the photons staying on the GPU: a PhotonMap (its .n = photons)."""
+        lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+        dirs2 = np.ascontiguousarray(dirs2, dtype=np.float64).reshape(lights.shape[0], -1, 2)
+        h, count = _vp(), C.c_uint64()
+        self.ctx._check(lib.rtg_photon_map_emit(self._h, _ptr(lights), lights.shape[0], _ptr(dirs2), dirs2.shape[1], max_depth,
+                                                C.byref(h), C.byref(count)))
+        return PhotonMap(self.ctx, None, n=count.value, _handle=h)
+
+    def photons_emit_raw(self, lights, dirs2, out_ptr, capacity, max_depth=4):
+        """The photon pass into caller-chosen memory (host or device address of `capacity` records): photons made."""
+        lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+        dirs2 = np.ascontiguousarray(dirs2, dtype=np.float64).reshape(lights.shape[0], -1, 2)
+        count = C.c_uint64()
+        self.ctx._check(lib.rtg_photons_emit(self._h, _ptr(lights), lights.shape[0], _ptr(dirs2), dirs2.shape[1], max_depth,
+                                             _ptr(out_ptr) if capacity else None, capacity, C.byref(count)))
+        return count.value
+
     def indirect_irrad(self, photon_map, points, photon_samples=3, newton_steps=5, newton_epsilon=1e-5):
         """compute_indirect_irrad per point: (n, 3) float64."""
         points = np.ascontiguousarray(points, dtype=POINT_DTYPE)
@@ -841,6 +873,16 @@ def render_scene_builder(ctx, time, width, height, max_depth=4):
     hits = np.empty(height * width, dtype=HIT_DTYPE)
     ctx._check(host.rth_render_scene_builder(ctx._h, time, width, height, max_depth, _ptr(rgb), _ptr(hits)))
     return rgb, hits
+
+
+def render_scene_builder_photons(ctx, time, width, height, photon_count, seed=1, max_depth=4):
+    """Renderer::render with its photon pass at width x height: (rgb, photons made, seconds of the three parts)."""
+    rgb = np.empty((height * width, 3), dtype=np.float64)
+    n = C.c_uint64()
+    seconds = (C.c_double * 3)()
+    ctx._check(host.rth_render_scene_builder_photons(ctx._h, time, width, height, max_depth, photon_count, seed, _ptr(rgb),
+                                                     C.byref(n), seconds))
+    return rgb, n.value, tuple(seconds)
 
 
 def to_hdr(rgb, width, height):

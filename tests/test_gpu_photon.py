@@ -73,6 +73,36 @@ def test_nearest_photons_reference_cases(gpu_ctx):
         pm.close()
 
 
+def test_nearest_photons_every_small_size(gpu_ctx):
+    """Trees of 1..40 photons (every shape the level-by-level build meets near its last levels), with repeated
+    coordinates, signed zeros and an infinite coordinate, against the brute-force sort."""
+    rng = np.random.default_rng(5)
+    for n in list(range(1, 41)) + [63, 64, 65, 127, 128, 129, 1000]:
+        ph = np.zeros(n, dtype=rtg.PHOTON_DTYPE)
+        pos = np.round(rng.random((n, 3)) * 8.0) - 4.0        # many equal coordinates
+        pos[pos == 0.0] = rng.choice([0.0, -0.0], size=int((pos == 0.0).sum()))
+        if n > 4:
+            pos[3, 0] = np.inf
+        ph["position"] = pos
+        pm = rtg.PhotonMap(gpu_ctx, ph)
+        kd = orc.OracleKd(pos)
+        q = np.concatenate([rng.random((16, 3)) * 10.0 - 5.0, pos[: min(n, 4)]])
+        q = q[np.isfinite(q).all(axis=1)]
+        for k in (1, 2, 3, 5, 16):
+            idx, dist = pm.nearest(q, k)
+            bidx, bdist = kd.nearest_brute(q, k)
+            assert np.array_equal(dist, bdist), (n, k)
+            found = idx != rtg.RTG_NONE
+            assert (found.sum(axis=1) == min(n, k)).all()
+            for row, drow, qrow in zip(idx, dist, q):          # every id carries its distance and appears once
+                ids = row[row != rtg.RTG_NONE]
+                assert np.unique(ids).size == ids.size
+                with np.errstate(invalid="ignore"):
+                    assert np.array_equal(np.sqrt((((qrow - pos[ids]) ** 2)[:, 0] + ((qrow - pos[ids]) ** 2)[:, 1])
+                                                  + ((qrow - pos[ids]) ** 2)[:, 2]), drow[: ids.size])
+        pm.close()
+
+
 def test_nearest_photons_large(gpu_ctx):
     rng = np.random.default_rng(11)
     n = 300_000
@@ -152,6 +182,46 @@ def test_photon_pass_matches_the_oracle(gpu_ctx):
         pair.gpu.photons_emit(lights, dirs, capacity=10)
     assert err.value.code == -6
     assert pair.gpu.photons_emit(lights, dirs[:, :0]).shape[0] == 0
+
+
+def test_photons_stay_on_the_device(gpu_ctx):
+    """The photon pass into device memory and a photon map made from that memory give what the host round trip
+    gives: same records, same nearest photons."""
+    import torch
+    objs, lights, view = scenes.default_objects(0)
+    scene = gpu_ctx.scene(objs)
+    dirs = np.stack([rtg.fibonacci_zenith_y(30_000, seed=3 + l) for l in range(2)])
+    host = scene.photons_emit(_lights(lights), dirs)
+    assert host.shape[0] > 500
+    room = host.shape[0] + 10
+    dev = torch.zeros(room * rtg.PHOTON_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+    made = scene.photons_emit_raw(_lights(lights), dirs, dev.data_ptr(), room)
+    gpu_ctx.synchronize()
+    assert made == host.shape[0]
+    back = np.frombuffer(dev.cpu().numpy().tobytes(), dtype=rtg.PHOTON_DTYPE)[:made]
+    assert back.tobytes() == host.tobytes()
+    pm_dev = rtg.PhotonMap(gpu_ctx, dev.data_ptr(), n=made)
+    pm_host = rtg.PhotonMap(gpu_ctx, host)
+    q = host["position"][::7] + 1e-3
+    for k in (1, 3):
+        a, b = pm_dev.nearest(q, k), pm_host.nearest(q, k)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # too little room: the count comes back with the error
+    with pytest.raises(rtg.RtgError) as err:
+        scene.photons_emit_raw(_lights(lights), dirs, dev.data_ptr(), 100)
+    assert err.value.code == -6
+    # the pass and the tree in one call
+    pm_one = scene.photon_map(_lights(lights), dirs)
+    assert pm_one.n == made
+    for k in (1, 3):
+        a, b = pm_one.nearest(q, k), pm_host.nearest(q, k)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    pm_one.close()
+    empty = scene.photon_map(_lights(lights), np.zeros((2, 0, 2)))
+    assert empty.n == 0 and (empty.nearest(q[:3], 2)[0] == rtg.RTG_NONE).all()
+    empty.close()
+    pm_dev.close()
+    pm_host.close()
 
 
 def test_photon_pass_through_meshes(gpu_ctx):
@@ -284,3 +354,26 @@ def test_frame_with_the_photon_term(gpu_ctx):
         empty = rtg.PhotonMap(gpu_ctx, photons[:0])
         e_rgb, _ = pair.gpu.render_frame_photons(view, lights, empty, w, h)
         assert not scenes.float_bits_differ(e_rgb, plain).any()
+
+
+def test_renderer_with_its_photon_pass(gpu_ctx):
+    """The host Renderer with the photon pass switched on (Renderer::render, src/render/renderer.rs:115-154) against
+    the same steps taken one by one on the oracle: directions, photon pass, k-d tree, pixel pass."""
+    time, w, h, count, seed = 7, 72, 72, 150_000, 5
+    got, n_photons, seconds = rtg.render_scene_builder_photons(gpu_ctx, time, w, h, count, seed=seed)
+    objs, lights, view = scenes.default_objects(time)
+    lights = _lights(lights)
+    pair = scenes.Pair(gpu_ctx, objs, {})
+    dirs = np.stack([rtg.fibonacci_zenith_y(count, seed=(seed + 0x9E3779B97F4A7C15 * l) % 2 ** 64) for l in range(2)])
+    photons = pair.cpu.photons_emit(lights, dirs)
+    assert n_photons == photons.shape[0] and n_photons > 1000
+    kd = orc.OracleKd(photons["position"])
+    want, _ = pair.cpu.render_frame_photons(view, lights, kd, photons, w, h)
+    plain, _ = rtg.render_scene_builder(gpu_ctx, time, w, h)
+    caustic = (want != plain).any(axis=1)
+    assert caustic.sum() > 50
+    assert not scenes.float_bits_differ(got[~caustic], plain[~caustic]).any()
+    close = np.isclose(got[caustic], want[caustic], rtol=IRRAD_RTOL, atol=1e-300).all(axis=1)
+    assert close.mean() > 0.99, close.mean()
+    assert all(x >= 0.0 for x in seconds)
+

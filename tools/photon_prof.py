@@ -40,7 +40,7 @@ photons, _ = timed(f"photon pass, {lights.shape[0]} x {count} directions", lambd
 print(f"  photons kept: {photons.shape[0]}  by bounces {np.bincount(photons['n_bounces']).tolist()}")
 t = time.perf_counter()
 pm = rtg.PhotonMap(ctx, photons)
-print(f"{'k-d tree build (host) + upload':42s} {(time.perf_counter() - t) * 1e3:10.2f} ms")
+print(f"{'k-d tree build (device) + upload':42s} {(time.perf_counter() - t) * 1e3:10.2f} ms")
 
 hits, pts, _ = scene.render_primary(view, side, side, points=True)
 q = np.ascontiguousarray(pts["position"])
