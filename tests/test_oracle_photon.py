@@ -207,3 +207,26 @@ def test_indirect_irradiance_of_the_caustic():
     # and a miss (manifold_len 0) is black
     miss = np.zeros(1, dtype=rtg.POINT_DTYPE)
     assert (pair.cpu.indirect_irrad(kd, photons, miss, 3, 5, 1e-5) == 0).all()
+
+
+def _splitmix_uniforms(seed, n):
+    """Draws 1..n of the SplitMix64 stream the host generators use, as doubles in [0, 1)."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def test_host_direction_generator_matches_the_plain_loop():
+    """The host library shares a photon pass's directions among threads and takes `x % (2 pi)` with a fused
+    multiply-add; the oracle's generator is the plain sequential loop over the library fmod.  Same bits from the
+    same draws, also at the reference's default of 10 000 000 directions per light (quotients in the millions)."""
+    from raytracer_amd import rtg
+    for count, seed in ((1, 1), (7, 2), (65_535, 3), (65_536, 4), (1_000_003, 5), (10_000_000, 6)):
+        a = rtg.fibonacci_zenith_y(count, seed=seed)
+        u = np.ascontiguousarray(_splitmix_uniforms(seed, 2 * count).reshape(count, 2))
+        b = np.empty((count, 2), dtype=np.float64)
+        orc.lib.orc_fibonacci_sphere(count, u.ctypes.data, b.ctypes.data)
+        assert a.tobytes() == b.tobytes(), (count, seed)
