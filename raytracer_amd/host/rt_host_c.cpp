@@ -139,7 +139,13 @@ int rth_render_scene_builder_photons(rtg_ctx *ctx, uint64_t time, uint32_t width
     if (out_rgb) std::memcpy(out_rgb, r.radiosity().data(), r.radiosity().size() * sizeof(double));
     return RTG_OK;
 }
+// bytes of one Radiance picture: the text header and four bytes per pixel
+static uint64_t hdr_bytes(uint32_t width, uint32_t height) {
+    return std::strlen("#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y  +X \n") + std::to_string(height).size() + std::to_string(width).size() +
+           (uint64_t)width * height * 4;
+}
 uint64_t rth_to_hdr(const double *rgb, uint32_t width, uint32_t height, uint8_t *out, uint64_t cap) {
+    if (!out) return hdr_bytes(width, height);          // sizing call: nothing is encoded
     std::vector<uint8_t> b = rt::to_hdr(rgb, width, height);
     if (out && cap >= b.size()) std::memcpy(out, b.data(), b.size());
     return b.size();
@@ -147,11 +153,13 @@ uint64_t rth_to_hdr(const double *rgb, uint32_t width, uint32_t height, uint8_t 
 void rth_fibonacci_sphere(uint64_t count, uint64_t seed, double *dirs3) { rt::fibonacci_sphere(count, seed, dirs3); }
 void rth_fibonacci_zenith_y(uint64_t count, uint64_t seed, double *dirs2) { rt::fibonacci_zenith_y(count, seed, dirs2); }
 uint64_t rth_images_tar(const double *rgb, uint32_t width, uint32_t height, double seconds, uint8_t *out, uint64_t cap) {
+    if (!out)                                           // sizing call: three members (header block + padded bytes), two end blocks
+        return 3 * (512 + (hdr_bytes(width, height) + 511) / 512 * 512) + 1024;
     std::map<std::string, std::vector<uint8_t>> images;                    // Renderer::images (renderer.rs:379-385)
     const size_t n = (size_t)width * height * 3;
     images["image.hdr"] = rt::to_hdr(rgb, width, height);
     std::vector<double> pq(n);
-    for (size_t i = 0; i < n; i++) pq[i] = rt::smpte2048_encode(rgb[i] / 80.0);
+    rt::pq_encode(rgb, n, pq.data());
     images["image.pq.hdr"] = rt::to_hdr(pq.data(), width, height);
     std::vector<double> perf(n, seconds / ((double)width * height) * 3000.0);
     images["perf.hdr"] = rt::to_hdr(perf.data(), width, height);

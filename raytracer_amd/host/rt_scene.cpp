@@ -5,7 +5,9 @@
 
 #include <chrono>
 #include <cmath>
+#include <algorithm>
 #include <cstring>
+#include <thread>
 
 namespace rt {
 
@@ -261,33 +263,68 @@ double smpte2048_encode(double x) {
 // Flat (run-length-free) Radiance picture: legal for every reader; the pixel
 // conversion is the shared-exponent RGBE of the `image` crate's HdrEncoder
 // that the reference calls (render/image.rs:63-64).
+// Rows [y0, y1) of a picture, shared among the host's cores: f(row range) for every range.
+template <class F> static void over_rows(uint32_t height, size_t work_per_row, F f) {
+    unsigned threads = std::thread::hardware_concurrency();
+    threads = threads > 16 ? 16 : threads;
+    if (threads < 2 || (size_t)height * work_per_row < (1u << 16) || height < threads) {
+        f(0u, height);
+        return;
+    }
+    std::vector<std::thread> pool;
+    uint32_t done = 0;
+    try {
+        pool.reserve(threads - 1);
+        for (unsigned t = 0; t + 1 < threads; t++) {
+            const uint32_t end = (uint32_t)((uint64_t)height * (t + 1) / threads);
+            pool.emplace_back(f, done, end);
+            done = end;
+        }
+    } catch (...) {
+        // no more threads to be had: the rest runs here
+    }
+    f(done, height);
+    for (auto &th : pool) th.join();
+}
+
 std::vector<uint8_t> to_hdr(const double *rgb, uint32_t width, uint32_t height) {
     std::string head = "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y " + std::to_string(height) + " +X " + std::to_string(width) + "\n";
-    std::vector<uint8_t> out(head.begin(), head.end());
-    out.reserve(out.size() + (size_t)width * height * 4);
-    for (uint32_t y = 0; y < height; y++)
-        for (uint32_t x = 0; x < width; x++) {
-            const double *p = rgb + ((size_t)y * width + x) * 3;
-            double c[3] = {p[0], p[1], p[2]};
-            if (c[0] != c[0] || c[1] != c[1] || c[2] != c[2]) {      // image.rs:52-58
-                double v = ((x + y) % 2 == 0) ? 0.0 : 1.0;
-                c[0] = c[1] = c[2] = v;
-            }
-            float f[3] = {(float)c[0], (float)c[1], (float)c[2]};
-            float mx = std::fmax(f[0], std::fmax(f[1], f[2]));
-            uint8_t px[4] = {0, 0, 0, 0};
-            if (mx > 0.0f) {
-                int e = (int)std::floor(std::log2(mx)) + 1;
-                float mul = std::ldexp(1.0f, e);
-                for (int k = 0; k < 3; k++) {
-                    float q = std::trunc(f[k] / mul * 256.0f);
-                    px[k] = (uint8_t)(q < 0.0f ? 0.0f : (q > 255.0f ? 255.0f : q));
+    std::vector<uint8_t> out(head.size() + (size_t)width * height * 4);
+    std::memcpy(out.data(), head.data(), head.size());
+    uint8_t *pixels = out.data() + head.size();
+    over_rows(height, width, [=](uint32_t y0, uint32_t y1) {
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = 0; x < width; x++) {
+                const double *p = rgb + ((size_t)y * width + x) * 3;
+                double c[3] = {p[0], p[1], p[2]};
+                if (c[0] != c[0] || c[1] != c[1] || c[2] != c[2]) {      // image.rs:52-58
+                    double v = ((x + y) % 2 == 0) ? 0.0 : 1.0;
+                    c[0] = c[1] = c[2] = v;
                 }
-                px[3] = (uint8_t)(e + 128);
+                float f[3] = {(float)c[0], (float)c[1], (float)c[2]};
+                float mx = std::fmax(f[0], std::fmax(f[1], f[2]));
+                uint8_t *px = pixels + ((size_t)y * width + x) * 4;
+                px[0] = px[1] = px[2] = px[3] = 0;
+                if (mx > 0.0f) {
+                    int e = (int)std::floor(std::log2(mx)) + 1;
+                    float mul = std::ldexp(1.0f, e);
+                    for (int k = 0; k < 3; k++) {
+                        float q = std::trunc(f[k] / mul * 256.0f);
+                        px[k] = (uint8_t)(q < 0.0f ? 0.0f : (q > 255.0f ? 255.0f : q));
+                    }
+                    px[3] = (uint8_t)(e + 128);
+                }
             }
-            out.insert(out.end(), px, px + 4);
-        }
+    });
     return out;
+}
+
+// ImageBuilder::smpte2048_encode (render/image.rs:33-43): every channel / 80 through the PQ curve.
+void pq_encode(const double *rgb, size_t n, double *out) {
+    over_rows((uint32_t)((n + 4095) / 4096), 4096, [=](uint32_t b0, uint32_t b1) {
+        const size_t end = std::min(n, (size_t)b1 * 4096);
+        for (size_t i = (size_t)b0 * 4096; i < end; i++) out[i] = smpte2048_encode(rgb[i] / 80.0);
+    });
 }
 
 std::map<std::string, std::vector<uint8_t>> Renderer::images() const {      // renderer.rs:379-385
@@ -296,7 +333,7 @@ std::map<std::string, std::vector<uint8_t>> Renderer::images() const {      // r
     if (rgb_.empty()) return r;
     r["image.hdr"] = to_hdr(rgb_.data(), w, h);
     std::vector<double> pq(rgb_.size());
-    for (size_t i = 0; i < rgb_.size(); i++) pq[i] = smpte2048_encode(rgb_[i] / 80.0);    // image.rs:39
+    pq_encode(rgb_.data(), rgb_.size(), pq.data());                                        // image.rs:39
     r["image.pq.hdr"] = to_hdr(pq.data(), w, h);
     // The reference's perf image is per-pixel CPU time x 3000; a GPU frame has one
     // time for all pixels, spread evenly.

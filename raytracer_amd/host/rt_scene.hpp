@@ -154,5 +154,6 @@ std::vector<uint8_t> to_hdr(const double *rgb, uint32_t width, uint32_t height);
 // The tar archive of Renderer::images() as the reference's server frames it (bin/server.rs:19-30).
 std::vector<uint8_t> images_tar(const std::map<std::string, std::vector<uint8_t>> &images);
 double smpte2048_encode(double x);   // geo/color.rs:15-17
+void pq_encode(const double *rgb, size_t n, double *out);   // render/image.rs:33-43 over n channel values
 
 } // namespace rt
