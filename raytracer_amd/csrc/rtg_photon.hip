@@ -500,6 +500,8 @@ __device__ __forceinline__ bool surface_of_point(const rtg_point &p, uint32_t &o
 
 // The Newton iteration of compute_indirect_irrad (render/renderer.rs:211-229): dir2[e] = the corrected ZenithY.
 // A pair without a photon, or whose point is a miss, gets NaN.
+// 256 registers, no scratch: builds held to 168 or 128 registers (three or four waves per SIMD) spill 260 / 396 bytes
+// per lane and run 24 % / 50 % longer
 __global__ __launch_bounds__(128) void k_newton(Pairs pr, uint32_t newton_steps, double *__restrict__ dir2) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= pr.n_points * pr.samples) return;
