@@ -173,6 +173,9 @@ def main():
                     help="frames in flight per GPU: that many contexts (one stream each) take the frames in turn")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the gather path even with one rank (rehearses the multi-GPU step on a 1-GPU box)")
+    ap.add_argument("--loopback", action="store_true",
+                    help="with --force-dist on one rank: the gather goes through RCCL (the rank sends to itself) instead "
+                         "of device copies, so RCCL's kernels run next to the traversal as they do with several ranks")
     ap.add_argument("--gather", choices=["native", "torch"], default="native",
                     help="native: rtg_gather_tiles behind the C ABI (RCCL send/recv); torch: torch.distributed.gather")
     args = ap.parse_args()
@@ -259,8 +262,12 @@ def main():
                     uid.copy_(torch.frombuffer(bytearray(rtg.comm_unique_id()), dtype=torch.uint8))
                 if world > 1:
                     dist.broadcast(uid, src=0)
-                comm = rtg.Comm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()) if world > 1 else None)
-                gather_kind = "rtg_gather_tiles (RCCL send/recv behind the C ABI)"
+                if world == 1 and args.loopback:      # rehearsal: one rank, but through RCCL (send / recv to itself)
+                    ctx.set_option("comm_loopback", 2)
+                    comm = rtg.Comm(ctx, 1, 0, rtg.comm_unique_id())
+                else:
+                    comm = rtg.Comm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()) if world > 1 else None)
+                gather_kind = "rtg_gather_tiles (RCCL send/recv behind the C ABI)" + (", one rank sending to itself" if world == 1 and args.loopback else "")
             except Exception as e:                    # noqa: BLE001 -- reported in the JSON line, not hidden
                 gather_kind = f"torch.distributed.gather (rtg_comm_create failed: {e})"
             if world > 1:                             # every rank must take the same path

@@ -239,6 +239,9 @@ int rtg_ctx_synchronize(rtg_ctx *ctx);
  *                                       GPU holds at once, 1280 for single-mesh scenes, 1024 otherwise)
  *   "pretest" 2 = on (default), 1 = off: single-precision box pre-test of traversal 2
  *   "stats" 2 = tally steps per phase in traversal 2 (diagnostics), 1 = off
+ *   "comm_loopback" 2 = a communicator created on the context afterwards goes through RCCL even with one rank (it
+ *                       needs an id then) and the root's own pieces travel by ncclSend / ncclRecv to itself: the
+ *                       several-rank machinery on a single GPU (diagnostics); 1 = off (default)
  *   "keep_state" 2 = traversal 2 runs the build made for scenes with several meshes (per-lane tree address, outer ray
  *                    kept) on any scene -- what a mesh of 2^27 nodes or more gets by itself; 1 = off (default)
  *   "frame_bands" 2 = rtg_render_frame issues an opaque scene's frame as two row bands on two streams, so one

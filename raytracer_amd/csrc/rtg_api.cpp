@@ -527,6 +527,10 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) try {
         ctx->tune.stats = value > 1 ? 1u : 0u;   // 2 = on, 1 = off (0 is rejected above as out of range)
         return RTG_OK;
     }
+    if (std::strcmp(key, "comm_loopback") == 0) {
+        ctx->comm_loopback = value > 1;          // 2 = on, 1 = off
+        return RTG_OK;
+    }
     if (std::strcmp(key, "keep_state") == 0) {
         ctx->tune.keep_state = value > 1 ? 1u : 0u;   // 2 = on, 1 = off
         return RTG_OK;

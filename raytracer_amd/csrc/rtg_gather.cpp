@@ -26,6 +26,7 @@ struct rtg_comm {
     int n_ranks = 1, rank = 0;
     ncclComm_t nccl = nullptr;
     bool owned = false;          // created here (destroyed here) or adopted from the caller
+    bool loopback = false;       // one rank, but through RCCL: the root sends its own pieces to itself
 };
 
 namespace {
@@ -114,7 +115,8 @@ int rtg_comm_create(rtg_ctx *ctx, const uint8_t id[RTG_COMM_ID_BYTES], int n_ran
     c->ctx = ctx;
     c->n_ranks = n_ranks;
     c->rank = rank;
-    if (n_ranks > 1) {                   // a single rank gathers with device copies alone
+    c->loopback = n_ranks == 1 && ctx->comm_loopback;
+    if (n_ranks > 1 || c->loopback) {    // a single rank gathers with device copies alone (unless asked otherwise)
         if (!id) {
             delete c;
             return api_fail(ctx, RTG_E_INVALID, "rtg_comm_create: id is null");
@@ -194,7 +196,7 @@ int rtg_gather_tiles(rtg_comm *comm, int root, const void *send, void *recv, con
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
 
     // the root's own pieces never leave the GPU
-    if (is_root)
+    if (is_root && !comm->loopback)
         for (uint32_t i = 0; i < n_pieces; i++) {
             const rtg_piece &p = pieces[i];
             if (p.rank != (uint32_t)root || p.bytes == 0) continue;
@@ -206,7 +208,7 @@ int rtg_gather_tiles(rtg_comm *comm, int root, const void *send, void *recv, con
                 return api_fail(ctx, RTG_E_HIP, "rtg_gather_tiles: device copy of piece %u: %s", i, hipGetErrorString(he));
             }
         }
-    if (comm->n_ranks == 1) return RTG_OK;
+    if (comm->n_ranks == 1 && !comm->loopback) return RTG_OK;
 
     // One group: the sends of a rank and the root's receives from it are matched in list order per peer.
     const Rccl &r = rccl();
@@ -216,7 +218,16 @@ int rtg_gather_tiles(rtg_comm *comm, int root, const void *send, void *recv, con
     uint32_t bad = 0;
     for (uint32_t i = 0; i < n_pieces && first == ncclSuccess; i++) {
         const rtg_piece &p = pieces[i];
-        if (p.bytes == 0 || p.rank == (uint32_t)root) continue;
+        if (p.bytes == 0) continue;
+        if (p.rank == (uint32_t)root) {
+            if (!comm->loopback || !is_root) continue;
+            if ((const uint8_t *)send + p.send_offset == (uint8_t *)recv + p.recv_offset) continue;   // rendered in place
+            first = r.Send((const uint8_t *)send + p.send_offset, (size_t)p.bytes, ncclUint8, root, comm->nccl, stream);
+            if (first == ncclSuccess)
+                first = r.Recv((uint8_t *)recv + p.recv_offset, (size_t)p.bytes, ncclUint8, root, comm->nccl, stream);
+            bad = i;
+            continue;
+        }
         if (is_root)
             first = r.Recv((uint8_t *)recv + p.recv_offset, (size_t)p.bytes, ncclUint8, (int)p.rank, comm->nccl, stream);
         else if (p.rank == (uint32_t)comm->rank)

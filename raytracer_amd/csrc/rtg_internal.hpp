@@ -30,6 +30,9 @@ struct rtg_ctx {
     // rtg_trace, summed by rtg_ctx_kernel_time
     bool time_kernels = false;
     bool sort_rays = false;      // option "sort_rays": rtg_trace orders the batch for coherence before tracing it
+    // option "comm_loopback": a communicator created on this context is a real RCCL communicator even with one rank,
+    // and the root's own pieces travel by ncclSend / ncclRecv to itself (the several-rank machinery on one GPU)
+    bool comm_loopback = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, idle_events;
     // rtg_render_frame renders a frame of an opaque scene as two row bands on two streams (option "frame_bands"):
     // `side` is an internal context (own stream and scratch) for the second band, joined back by events

@@ -48,3 +48,49 @@ def test_one_rank_gather_assembles_the_frame_from_strips(gpu_ctx):
         comm.gather(0, np.zeros(16, np.uint8), recv.data_ptr(), [(0, 0, 0, 16)])
     comm.close()
     scene.close()
+
+
+def test_one_rank_gather_through_rccl(gpu_ctx):
+    """The machinery several ranks use -- RCCL bound at run time, ncclGetUniqueId, ncclCommInitRank, one group of
+    ncclSend / ncclRecv on the caller's stream, ncclCommDestroy -- on a single GPU: with "comm_loopback" the one-rank
+    communicator is a real RCCL communicator and the root sends its own pieces to itself.  Same bytes as the copies,
+    also while a traversal runs on another stream."""
+    import torch
+    tris, xform = scenes.terrain(60, 60, seed=9)
+    mesh = gpu_ctx.mesh(rtg.HostBvh(tris))
+    scene = gpu_ctx.scene([rtg.mesh_object(mesh, rtg.material((1, 1, 1)), xform)])
+    view = rtg.make_view()
+    w, h = 640, 360
+    n = w * h * 16
+    whole = torch.empty(n, dtype=torch.uint8, device="cuda")
+    scene.render_primary_raw(view, w, h, (0, 0, w, h), whole.data_ptr())
+    plan = shard.tile_strips(w, h, world=1, interleave=9)
+    pieces = shard.strip_pieces(plan, w, 16)
+    send = torch.empty(n, dtype=torch.uint8, device="cuda")
+    for (x0, y0, tw, th), (_, so, _, nb) in zip(plan[0], pieces):
+        scene.render_primary_raw(view, w, h, (x0, y0, tw, th), send.data_ptr() + so)
+    gpu_ctx.synchronize()
+    gpu_ctx.set_option("comm_loopback", 2)
+    with pytest.raises(rtg.RtgError, match="id is null"):
+        rtg.Comm(gpu_ctx)
+    comm = rtg.Comm(gpu_ctx, 1, 0, rtg.comm_unique_id())
+    gpu_ctx.set_option("comm_loopback", 1)
+    recv = torch.full((n,), 0x5A, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    comm.gather(0, send.data_ptr(), recv.data_ptr(), pieces[::-1])
+    gpu_ctx.synchronize()
+    assert recv.cpu().numpy().tobytes() == whole.cpu().numpy().tobytes()
+    # on a second stream, next to a frame being traced on the context's stream (what bench.py --gpus N does)
+    st = torch.cuda.Stream()
+    busy = torch.empty(1920 * 1080 * 16, dtype=torch.uint8, device="cuda")
+    for _ in range(3):
+        recv.fill_(0)
+        torch.cuda.synchronize()
+        scene.render_primary_raw(view, 1920, 1080, (0, 0, 1920, 1080), busy.data_ptr())
+        comm.gather(0, send.data_ptr(), recv.data_ptr(), pieces, stream_handle=st.cuda_stream)
+        st.synchronize()
+        gpu_ctx.synchronize()
+        assert recv.cpu().numpy().tobytes() == whole.cpu().numpy().tobytes()
+    comm.close()
+    scene.close()
+
