@@ -307,8 +307,8 @@ __device__ __forceinline__ bool rc_less(double a, double b) { return real_cmp(a,
 
 template <int K>
 __global__ __launch_bounds__(128) void k_kd_nearest(const KdNode *__restrict__ nodes, uint32_t n, const double *__restrict__ queries3,
-                                                    uint64_t n_queries, uint32_t k, uint32_t *__restrict__ out_index,
-                                                    double *__restrict__ out_distance) {
+                                                    uint64_t n_queries, uint32_t k, uint32_t stack_cap,
+                                                    uint32_t *__restrict__ out_index, double *__restrict__ out_distance) {
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_queries) return;
     const V3 query = ld3(queries3 + q * 3);
@@ -358,18 +358,21 @@ __global__ __launch_bounds__(128) void k_kd_nearest(const KdNode *__restrict__ n
         return top;
     };
     // nearest_rec (tree/kd_tree.rs:122-154) with its own stack: a frame is (begin, len) plus whether the first
-    // subtree has been searched already.  A balanced tree over n < 2^31 entries is at most 31 levels deep and a
-    // level holds one suspended frame, the innermost one two.
-    constexpr int kStack = 40;
-    uint32_t st_begin[kStack], st_len[kStack];
+    // subtree has been searched already.  A balanced tree over n entries is floor(log2 n) + 1 levels deep and a
+    // level holds one suspended frame, the innermost one two: `stack_cap` frames per lane, kept in LDS (frame f of
+    // lane t at f * blockDim + t: no bank conflicts).  As a per-lane array the stack is indexed dynamically and lives
+    // in scratch memory, which for a full GPU of waves does not fit L2 and moved 4.6 GB per 2 M queries.
+    extern __shared__ unsigned long long kd_stack[];
+    const uint32_t lane_slot = threadIdx.x, stride = blockDim.x;
+    const int kStack = (int)stack_cap;
     int sp = 0;
-    st_begin[0] = 0;
-    st_len[0] = n;
+    kd_stack[lane_slot] = (unsigned long long)n << 32;
     sp = 1;
     while (sp > 0 && k != 0) {
         sp--;
-        const uint32_t begin = st_begin[sp];
-        const uint32_t raw = st_len[sp];
+        const unsigned long long frame = kd_stack[(uint32_t)sp * stride + lane_slot];
+        const uint32_t begin = (uint32_t)frame;
+        const uint32_t raw = (uint32_t)(frame >> 32);
         const bool resumed = (raw & 0x80000000u) != 0;
         const uint32_t len = raw & 0x7FFFFFFFu;
         if (len == 0) continue;
@@ -401,19 +404,18 @@ __global__ __launch_bounds__(128) void k_kd_nearest(const KdNode *__restrict__ n
                 if (__builtin_sqrt(total) > heap_top()) continue;
             }
             if (sp + 2 > kStack) break;       // cannot happen for a balanced tree; never write past the stack
-            st_begin[sp] = begin;
-            st_len[sp] = len | 0x80000000u;
+            kd_stack[(uint32_t)sp * stride + lane_slot] = ((unsigned long long)(len | 0x80000000u) << 32) | begin;
             sp++;
-            st_begin[sp] = left_first ? l_begin : r_begin;
-            st_len[sp] = left_first ? l_len : r_len;
+            kd_stack[(uint32_t)sp * stride + lane_slot] =
+                ((unsigned long long)(left_first ? l_len : r_len) << 32) | (left_first ? l_begin : r_begin);
             sp++;
         } else {
             heap_push(length(query - pos), node->value);
             bool more = size < k;
             if (!more) more = __builtin_fabs(qa - pa) < heap_top();
             if (more) {
-                st_begin[sp] = left_first ? r_begin : l_begin;
-                st_len[sp] = left_first ? r_len : l_len;
+                kd_stack[(uint32_t)sp * stride + lane_slot] =
+                    ((unsigned long long)(left_first ? r_len : l_len) << 32) | (left_first ? r_begin : l_begin);
                 sp++;
             }
         }
@@ -731,7 +733,12 @@ __global__ __launch_bounds__(256) void k_frame_pq8(const double *__restrict__ rg
 
 template <int K>
 void launch_kd(hipStream_t stream, const void *nodes, uint32_t n, const double *q, uint64_t nq, uint32_t k, uint32_t *oi, double *od) {
-    hipLaunchKernelGGL(k_kd_nearest<K>, dim3((uint32_t)((nq + 127) / 128)), dim3(128), 0, stream, (const KdNode *)nodes, n, q, nq, k, oi, od);
+    // frames a lane can have suspended: one per level of the tree and two for the innermost (n = 0: the root frame)
+    uint32_t levels = 1;
+    while (levels < 32 && (n >> levels) != 0) levels++;
+    const uint32_t cap = levels + 2;
+    hipLaunchKernelGGL(k_kd_nearest<K>, dim3((uint32_t)((nq + 127) / 128)), dim3(128), (size_t)cap * 128 * sizeof(unsigned long long),
+                       stream, (const KdNode *)nodes, n, q, nq, k, cap, oi, od);
 }
 
 } // namespace
