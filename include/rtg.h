@@ -393,8 +393,10 @@ typedef struct rtg_photon_map rtg_photon_map;
  * from an entropy-seeded generator, so the caller supplies them) the ray from the light's centre is followed
  * through `raytrace_all_specular` and every hit behind at least one specular bounce becomes a photon.  Directions
  * are turned into rays on the host (`ZenithY::into_normal` uses the platform's sin/cos, as the reference does); the
- * paths are traced on the GPU.  max_depth is the reference's constant 4 (at most 4).  When more than `capacity`
- * photons result nothing is written and RTG_E_LIMIT is returned; *n_photons is set either way. */
+ * paths are traced on the GPU.  max_depth is the reference's constant 4 (at most 4).  out_photons may be
+ * host or device memory.  When more than `capacity` photons result, RTG_E_LIMIT is returned and the buffer's contents
+ * are unspecified (the batches that still fitted have been written); *n_photons is set either way, so a second call
+ * with that much room succeeds. */
 int rtg_photons_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const double *dirs2,
                      uint64_t count_per_light, uint32_t max_depth, rtg_photon *out_photons, uint64_t capacity,
                      uint64_t *n_photons);

@@ -134,6 +134,10 @@ hipError_t launch_kd_nearest(hipStream_t stream, const void *nodes, uint32_t n_n
 // the longest photon path (capped at 3) and the index of the first photon with a NaN coordinate (or 0xFFFFFFFF).
 size_t kd_build_scratch_bytes(uint32_t n);
 hipError_t build_kd_device(hipStream_t stream, const rtg_photon *photons, uint32_t n, void *scratch, void *nodes, uint32_t **summary);
+// The rays of a batch of emission directions and their (zenith, y) pairs from `staged` (cos zenith, sin zenith,
+// zenith, y per direction, device memory).
+hipError_t launch_photon_rays(hipStream_t stream, const double *staged, uint32_t n, const rtg_light *lights, uint64_t first_ray,
+                              uint64_t count_per_light, double *rays6, double *dirs2);
 // Photons of one batch of path records: flags + exclusive scan (offsets[i] = photons before path i) + records
 // written at out[offsets[i]] while that is below `room`.
 size_t photon_scan_temp_bytes(uint32_t n);

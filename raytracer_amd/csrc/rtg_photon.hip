@@ -428,7 +428,25 @@ __global__ __launch_bounds__(128) void k_kd_nearest(const KdNode *__restrict__ n
         }
 }
 
-// ---- the photon pass: paths -> photons ---------------------------------------------------------------------
+// ---- the photon pass: directions -> rays, paths -> photons --------------------------------------------------
+// Ray::new(light.sphere.orig(), dir.into_normal()) (render/renderer.rs:123, geo/sphere.rs:29-34) with the cosine and
+// sine of the zenith taken on the host (`staged` holds cos, sin, zenith, y per direction): the square root and the
+// two products round on the device as they do on the host.
+__global__ __launch_bounds__(256) void k_photon_rays(const double *__restrict__ staged, uint32_t n, const rtg_light *__restrict__ lights,
+                                                     uint64_t first_ray, uint64_t count_per_light, double *__restrict__ rays6,
+                                                     double *__restrict__ dirs2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double2 cs = reinterpret_cast<const double2 *>(staged)[(size_t)i * 2];
+    const double2 zy = reinterpret_cast<const double2 *>(staged)[(size_t)i * 2 + 1];
+    const rtg_light &light = lights[(first_ray + i) / count_per_light];
+    const double radius = __builtin_sqrt(1.0 - zy.y * zy.y);
+    double2 *w = reinterpret_cast<double2 *>(rays6 + (size_t)i * 6);
+    w[0] = make_double2(light.position[0], light.position[1]);
+    w[1] = make_double2(light.position[2], cs.x * radius);
+    w[2] = make_double2(zy.y, cs.y * radius);
+    reinterpret_cast<double2 *>(dirs2)[i] = zy;
+}
 __global__ __launch_bounds__(256) void k_photon_flags(const rtg_path *__restrict__ paths, uint32_t n, uint32_t *__restrict__ flags) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flags[i] = paths[i].depth >= 1 ? 1u : 0u;      // `if path.modes.len() == 0 { return None }`
@@ -779,6 +797,13 @@ hipError_t launch_photons_from_paths(hipStream_t stream, const rtg_path *paths, 
     return hipGetLastError();
 }
 
+hipError_t launch_photon_rays(hipStream_t stream, const double *staged, uint32_t n, const rtg_light *lights, uint64_t first_ray,
+                              uint64_t count_per_light, double *rays6, double *dirs2) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_photon_rays, dim3((n + 255) / 256), dim3(256), 0, stream, staged, n, lights, first_ray, count_per_light, rays6,
+                       dirs2);
+    return hipGetLastError();
+}
 hipError_t launch_camera_rays(hipStream_t stream, const rtg_view &view, uint32_t width, uint32_t height, rtg_rect tile, double *rays6) {
     const uint64_t n = (uint64_t)tile.w * tile.h;
     if (n == 0) return hipSuccess;

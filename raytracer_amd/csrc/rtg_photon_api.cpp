@@ -162,26 +162,29 @@ int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, c
     if ((rc = api_input(ctx, "photon_lights", lights, (size_t)n_lights * sizeof(rtg_light), &d_lights)) != RTG_OK) return rc;
     const uint64_t batch = 1ull << 19;                       // rays per rtg_trace_paths call (1.1 GB of path records at depth 4)
     const uint64_t per_ray = (1ull << max_depth) - 1;        // paths a ray can have
-    // ZenithY::into_normal (src/geo/sphere.rs:29-34); Ray::new(light.sphere.orig(), ..) (renderer.rs:123): two libm
-    // calls and a square root per direction, spread over the host's cores; the next batch's rays are made while the
-    // GPU traces this one
-    std::vector<double> rays[2];
-    rays[0].resize((size_t)std::min(batch, n_rays) * 6);
-    if (n_rays > batch) rays[1].resize((size_t)batch * 6);
+    // ZenithY::into_normal (src/geo/sphere.rs:29-34): the cosine and the sine of every zenith come from the host's
+    // libm, as two calls, spread over the host's cores; they go to the device together with the direction itself
+    // (32 bytes per direction through pinned memory, against 64 for finished rays and directions from pageable
+    // memory, which made the pass wait for PCIe); a kernel finishes the rays.  The next batch is prepared while the
+    // GPU traces this one.
+    struct Pinned {
+        double *p = nullptr;
+        ~Pinned() {
+            if (p) (void)hipHostFree(p);
+        }
+    } staging[2];
+    const size_t batch_doubles = (size_t)std::min(batch, n_rays) * 4;
+    HIP_TRY(ctx, hipHostMalloc((void **)&staging[0].p, batch_doubles * sizeof(double), hipHostMallocDefault));
+    if (n_rays > batch) HIP_TRY(ctx, hipHostMalloc((void **)&staging[1].p, batch_doubles * sizeof(double), hipHostMallocDefault));
     auto make_batch = [&](uint64_t first, double *dst) {
         api_parallel_ranges((size_t)std::min(batch, n_rays - first), 4096, [=](size_t begin, size_t end) {
             for (size_t i = begin; i < end; i++) {
-                const uint64_t r = first + i;
-                const rtg_light &light = lights[r / count_per_light];
-                const double zenith = dirs2[r * 2], y = dirs2[r * 2 + 1];
-                const double radius = std::sqrt(1.0 - y * y);
-                double *w = dst + i * 6;
-                w[0] = light.position[0];
-                w[1] = light.position[1];
-                w[2] = light.position[2];
-                w[3] = libm_cos(zenith) * radius;
-                w[4] = y;
-                w[5] = libm_sin(zenith) * radius;
+                const double zenith = dirs2[(first + i) * 2], y = dirs2[(first + i) * 2 + 1];
+                double *w = dst + i * 4;
+                w[0] = libm_cos(zenith);
+                w[1] = libm_sin(zenith);
+                w[2] = zenith;
+                w[3] = y;
             }
         });
     };
@@ -191,14 +194,14 @@ int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, c
             if (thread.joinable()) thread.join();
         }
     };
-    make_batch(0, rays[0].data());
+    make_batch(0, staging[0].p);
     uint64_t total = 0;
     for (uint64_t first = 0, b = 0; first < n_rays; first += batch, b++) {
         const uint64_t m = std::min(batch, n_rays - first);
-        const double *batch_rays = rays[b & 1].data();
+        const double *staged = staging[b & 1].p;
         Joined ahead;                                        // joined at the end of the iteration, however it ends
         if (first + batch < n_rays) {
-            double *dst = rays[(b + 1) & 1].data();
+            double *dst = staging[(b + 1) & 1].p;
             const uint64_t next_first = first + batch;
             try {
                 ahead.thread = std::thread([&make_batch, next_first, dst]() { make_batch(next_first, dst); });
@@ -206,13 +209,19 @@ int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, c
                 make_batch(next_first, dst);
             }
         }
-        void *d_paths = nullptr;
+        void *d_paths = nullptr, *d_staged = nullptr, *d_rays = nullptr, *d_dirs = nullptr;
         if ((rc = api_scratch(ctx, "photon_paths", (size_t)(m * per_ray) * sizeof(rtg_path), &d_paths)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "photon_staged", (size_t)m * 4 * sizeof(double), &d_staged)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "photon_rays", (size_t)m * 6 * sizeof(double), &d_rays)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "photon_dirs", (size_t)m * 2 * sizeof(double), &d_dirs)) != RTG_OK) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(d_staged, staged, (size_t)m * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, launch_photon_rays(ctx->stream, (const double *)d_staged, (uint32_t)m, (const rtg_light *)d_lights, first,
+                                        count_per_light, (double *)d_rays, (double *)d_dirs));
         uint64_t n_paths = 0;
-        if ((rc = rtg_trace_paths(scene, batch_rays, m, max_depth, (rtg_path *)d_paths, m * per_ray, &n_paths)) != RTG_OK) return rc;
+        if ((rc = rtg_trace_paths(scene, (const double *)d_rays, m, max_depth, (rtg_path *)d_paths, m * per_ray, &n_paths)) != RTG_OK)
+            return rc;
         if (n_paths == 0) continue;
         void *flags = nullptr, *offsets = nullptr, *temp = nullptr, *d_out = nullptr;
-        const void *d_dirs = nullptr;
         const size_t temp_bytes = photon_scan_temp_bytes((uint32_t)n_paths);
         if ((rc = api_scratch(ctx, "photon_flags", (size_t)n_paths * sizeof(uint32_t), &flags)) != RTG_OK) return rc;
         if ((rc = api_scratch(ctx, "photon_offsets", (size_t)n_paths * sizeof(uint32_t), &offsets)) != RTG_OK) return rc;
@@ -220,7 +229,6 @@ int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, c
         // a batch writes only what still fits the caller's room
         const uint64_t room = sink.grow ? n_paths : (sink.capacity > total ? std::min<uint64_t>(sink.capacity - total, n_paths) : 0);
         if ((rc = api_scratch(ctx, "photon_out", (size_t)std::max<uint64_t>(room, 1) * sizeof(rtg_photon), &d_out)) != RTG_OK) return rc;
-        if ((rc = api_input(ctx, "photon_dirs", dirs2 + first * 2, (size_t)m * 2 * sizeof(double), &d_dirs)) != RTG_OK) return rc;
         HIP_TRY(ctx, launch_photons_from_paths(ctx->stream, (const rtg_path *)d_paths, (uint32_t)n_paths, (const double *)d_dirs,
                                                (const rtg_light *)d_lights, first, count_per_light, (uint32_t *)flags,
                                                (uint32_t *)offsets, temp, temp_bytes, room, (rtg_photon *)d_out));

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <new>
 #include <numeric>
 
 #include "rt_bvh.hpp"
@@ -101,7 +102,7 @@ void rth_scene_builder(uint64_t time, rtg_object objects[2], rtg_light lights[2]
     *view = sb.view().c();
 }
 int rth_render_scene_builder(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32_t height, uint32_t max_depth,
-                             double *out_rgb, rtg_hit *out_hits) {
+                             double *out_rgb, rtg_hit *out_hits) try {
     rt::SceneBuilder sb;
     sb.time = time;
     rt::Scene scene = sb.scene();
@@ -114,10 +115,14 @@ int rth_render_scene_builder(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32
     if (out_rgb) std::memcpy(out_rgb, r.radiosity().data(), r.radiosity().size() * sizeof(double));
     if (out_hits) std::memcpy(out_hits, r.hits().data(), r.hits().size() * sizeof(rtg_hit));
     return RTG_OK;
+} catch (const std::bad_alloc &) {
+    return RTG_E_NOMEM;          // nothing unwinds into the caller, which need not be C++
+} catch (...) {
+    return RTG_E_INTERNAL;
 }
 int rth_render_scene_builder_photons(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32_t height, uint32_t max_depth,
                                      uint64_t photon_count, uint64_t seed, double *out_rgb, uint64_t *n_photons,
-                                     double seconds[3]) {
+                                     double seconds[3]) try {
     rt::SceneBuilder sb;
     sb.time = time;
     rt::Scene scene = sb.scene();
@@ -138,6 +143,10 @@ int rth_render_scene_builder_photons(rtg_ctx *ctx, uint64_t time, uint32_t width
     if (rc != RTG_OK) return rc;
     if (out_rgb) std::memcpy(out_rgb, r.radiosity().data(), r.radiosity().size() * sizeof(double));
     return RTG_OK;
+} catch (const std::bad_alloc &) {
+    return RTG_E_NOMEM;          // nothing unwinds into the caller, which need not be C++
+} catch (...) {
+    return RTG_E_INTERNAL;
 }
 // bytes of one Radiance picture: the text header and four bytes per pixel
 static uint64_t hdr_bytes(uint32_t width, uint32_t height) {
