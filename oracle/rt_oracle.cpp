@@ -1601,13 +1601,14 @@ void orc_kd_nearest_brute(const double *positions3, uint64_t n, const double *qu
 int orc_photons_emit(const orc_scene *s, const rtg_light *lights, uint32_t n_lights, const double *dirs2,
                      uint64_t count_per_light, uint32_t max_depth, rtg_photon *out, uint64_t capacity, uint64_t *n_photons) {
     uint64_t total = 0;
+    std::vector<PathPoint> paths;       // one buffer for all rays
     for (uint32_t l = 0; l < n_lights; l++) {
         const V3 origin = mk(lights[l].position[0], lights[l].position[1], lights[l].position[2]);
         const V3 color = mk(lights[l].color[0], lights[l].color[1], lights[l].color[2]);
         for (uint64_t i = 0; i < count_per_light; i++) {
             const double *dir = dirs2 + (l * count_per_light + i) * 2;
             gen::Vec3T<double> n = gen::zenith_y_into_normal<double>(dir[0], dir[1]);
-            std::vector<PathPoint> paths;
+            paths.clear();
             Counters c;
             all_specular_rec(*s, Ray{origin, mk(n[0], n[1], n[2])}, 1.0, 0, max_depth, paths, c);
             for (const PathPoint &pp : paths) {

@@ -45,7 +45,7 @@ if oracle_count:
     cpu = orc.OracleScene(objs)
     dirs = np.stack([rtg.fibonacci_zenith_y(oracle_count, seed=1 + l) for l in range(2)])
     t0 = time.perf_counter()
-    photons = cpu.photons_emit(lights, dirs)
+    photons = cpu.photons_emit(lights, dirs)                 # one thread (the oracle's photon pass is a plain loop)
     t1 = time.perf_counter()
     kd = orc.OracleKd(photons["position"])
     t2 = time.perf_counter()
@@ -53,6 +53,8 @@ if oracle_count:
     t3 = time.perf_counter()
     scale = count / oracle_count
     est = (t1 - t0) * scale + (t2 - t1) * scale + (t3 - t2)
+    ideal = (t1 - t0) * scale / orc.THREADS + (t2 - t1) * scale + (t3 - t2)
     print(f"oracle, {orc.THREADS} threads for the pixel pass, 1 for the photon pass: {2 * oracle_count} directions {1e3 * (t1 - t0):.0f} ms "
           f"({2 * oracle_count / (t1 - t0) / 1e6:.2f} M/s), tree of {photons.shape[0]} photons {1e3 * (t2 - t1):.0f} ms, pixel pass "
-          f"{1e3 * (t3 - t2):.0f} ms; scaled to {2 * count} directions: about {est:.1f} s per frame")
+          f"{1e3 * (t3 - t2):.0f} ms; scaled to {2 * count} directions: about {est:.1f} s per frame "
+          f"({ideal:.2f} s if the photon pass were spread over {orc.THREADS} threads without loss)")
