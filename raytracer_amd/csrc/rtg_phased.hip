@@ -506,12 +506,18 @@ static_assert(kPhasedBlock % 64 == 0 && kPhasedBlock >= 64 && kPhasedBlock <= 25
 
 // Waves per SIMD the kernel is compiled for.  The lean variants -- one mesh, triangles, no counters -- fit 96
 // registers and 8 KB of LDS per wave, so five waves share a SIMD (20 per CU: all of its 160 KB of LDS); the others
-// (several meshes, patches, counting, statistics) keep more state and stay at four.
+// (several meshes, counting, statistics) keep more state and stay at four; patch scenes run at three (below).
 #ifndef RTG_PHASED_WAVES_LEAN
 #define RTG_PHASED_WAVES_LEAN 5
 #endif
+// Patch scenes keep the Newton solve's state as well: at four waves (128 registers) the kernel spills 180 bytes per
+// lane and moves 4.5 GB of scratch traffic per 3840x2160 frame; at three (166 registers, 20 bytes) the frame is 8 %
+// faster, at two slower again.
+#ifndef RTG_PHASED_WAVES_PATCH
+#define RTG_PHASED_WAVES_PATCH 3
+#endif
 constexpr int phased_waves(bool five_ok, bool count, bool patch, bool keep, bool stats) {
-    return (!five_ok || count || patch || keep || stats) ? RTG_PHASED_WAVES : RTG_PHASED_WAVES_LEAN;
+    return patch ? RTG_PHASED_WAVES_PATCH : ((!five_ok || count || keep || stats) ? RTG_PHASED_WAVES : RTG_PHASED_WAVES_LEAN);
 }
 
 template <class Source, bool COUNT, bool PATCH, bool PRE, bool KEEP, bool STATS = false>

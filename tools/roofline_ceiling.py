@@ -61,7 +61,8 @@ def main():
                "fractions": {"l1": round(f1, 5), "l2": round(f2, 5), "beyond_l2": round(f3, 5), "source": os.path.relpath(pmc)},
                "ceiling_lane_loads_per_s": lane_loads_per_s, "ceiling_visits_per_s": lane_loads_per_s / loads,
                "model": "1 / (f1/r1 + f2/r2 + f3/r3) / loads_per_visit"}
-    with open(os.path.join(d, "ceiling.json" if "config2" in workload else "ceiling_c4.json"), "w") as f:
+    suffix = "" if "config2" in workload else ("_c4" if "config4" in workload else "_" + re.sub(r"\W+", "_", workload))
+    with open(os.path.join(d, f"ceiling{suffix}.json"), "w") as f:
         json.dump(ceiling, f, indent=1)
     kb = 1024.0
     traffic = {"workload": workload, "kernel": kernel, "source": os.path.relpath(pmc),
@@ -74,7 +75,7 @@ def main():
         traffic["read_requests"] = {"all": n_all, "of_128_bytes": n128, "of_64_bytes": n64,
                                     "bytes_by_request_size": 128.0 * n128 + 64.0 * n64 + 32.0 * max(0.0, n_all - n128 - n64),
                                     "fetch_size_doubled_bytes": 2.0 * c["FETCH_SIZE"] * kb}
-    with open(os.path.join(d, "traffic.json" if "config2" in workload else "traffic_c4.json"), "w") as f:
+    with open(os.path.join(d, f"traffic{suffix}.json"), "w") as f:
         json.dump(traffic, f, indent=1)
     print(json.dumps(ceiling, indent=1))
     print(json.dumps(traffic, indent=1))
