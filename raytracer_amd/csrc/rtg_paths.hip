@@ -7,6 +7,8 @@
 // ray the order the recursion pushes them, which is the pre-order index -- by one radix sort on (ray, index).
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "rtg_device.hpp"
@@ -33,8 +35,16 @@ __global__ __launch_bounds__(kBlock) void k_path_emit(const SpecMeta *__restrict
                                                        uint32_t max_depth, uint32_t *counter, uint64_t *keys,
                                                        rtg_path *records) {
     uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= n) return;
-    if (points[gid].manifold_len == 0) return;
+    const bool emits = gid < n && points[gid].manifold_len != 0;
+    // one counter update per wave: its lanes that have a record take consecutive places
+    const uint64_t emitting = __ballot(emits);
+    if (emitting == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == (uint32_t)(__ffsll((unsigned long long)emitting) - 1)) base = atomicAdd(counter, (uint32_t)__popcll(emitting));
+    base = __shfl(base, __ffsll((unsigned long long)emitting) - 1, 64);
+    if (!emits) return;
+    const uint32_t idx = base + (uint32_t)__popcll(emitting & ((1ull << lane) - 1ull));
     const SpecMeta me = meta[gid];
     // walk down from the root to the node with pre-order index `slot`: the reflected subtree comes first
     uint32_t at = 0, depth = 0, modes = 0, parent = 0xFFFFFFFFu;
@@ -49,7 +59,6 @@ __global__ __launch_bounds__(kBlock) void k_path_emit(const SpecMeta *__restrict
         }
         depth++;
     }
-    const uint32_t idx = atomicAdd(counter, 1u);
     keys[idx] = ((uint64_t)me.group << 8) | me.slot;
     rtg_path r;
     r.ray = me.group;
@@ -79,12 +88,24 @@ __global__ __launch_bounds__(kBlock) void k_path_gather(LevelTable table, uint32
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n) return;
     const uint32_t src = sorted_source[p];
-    uint32_t level = 0;
-    while (level + 1 < n_levels && src >= table.first[level + 1]) level++;
-    rtg_path r = table.records[level][src - table.first[level]];
-    if (r.parent != 0xFFFFFFFFu) {
+    // the level whose records hold `src`, picked with constant indices: a variable index would make the compiler
+    // copy the table to scratch memory
+    const rtg_path *records = table.records[0];
+    uint32_t first = table.first[0];
+#pragma unroll
+    for (uint32_t l = 1; l < 8; l++)
+        if (l < n_levels && src >= table.first[l]) {
+            records = table.records[l];
+            first = table.first[l];
+        }
+    // a record moves as nine 16-byte words; the first holds ray, depth, modes and parent
+    static_assert(sizeof(rtg_path) == 144 && offsetof(rtg_path, parent) == 12, "path record layout");
+    const uint4 *from = reinterpret_cast<const uint4 *>(records + (src - first));
+    uint4 *to = reinterpret_cast<uint4 *>(out + p);
+    uint4 head = from[0];
+    if (head.w != 0xFFFFFFFFu) {
         // the parent's record sits before this one: lower pre-order index of the same ray
-        const uint64_t want = ((uint64_t)r.ray << 8) | r.parent;
+        const uint64_t want = ((uint64_t)head.x << 8) | head.w;
         uint32_t lo = 0, hi = p;
         while (lo < hi) {
             uint32_t mid = lo + (hi - lo) / 2;
@@ -93,9 +114,11 @@ __global__ __launch_bounds__(kBlock) void k_path_gather(LevelTable table, uint32
             else
                 hi = mid;
         }
-        r.parent = lo;
+        head.w = lo;
     }
-    out[p] = r;
+    to[0] = head;
+#pragma unroll
+    for (int k = 1; k < 9; k++) to[k] = from[k];
 }
 
 inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + kBlock - 1) / kBlock)); }

@@ -481,11 +481,15 @@ __global__ __launch_bounds__(256) void k_photon_write(const rtg_path *__restrict
     uint32_t at = p.parent;                                   // ancestors, deepest first
     for (uint32_t d = p.depth; d-- > 0 && at < n;) {
         const rtg_path &a = paths[at];
-        if (d < 3) {
-            const uint32_t len = a.point.manifold_len;
-            ph.surface_object[d] = len == 2 ? a.point.manifold[1] : a.point.manifold[0];
-            ph.surface_leaf[d] = len == 2 ? a.point.manifold[0] : RTG_NONE;
-        }
+        const uint32_t len = a.point.manifold_len;
+        const uint32_t object = len == 2 ? a.point.manifold[1] : a.point.manifold[0];
+        const uint32_t leaf = len == 2 ? a.point.manifold[0] : RTG_NONE;
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++)      // constant indices keep the record in registers
+            if (k == d) {
+                ph.surface_object[k] = object;
+                ph.surface_leaf[k] = leaf;
+            }
         at = a.parent;
     }
     out[slot] = ph;

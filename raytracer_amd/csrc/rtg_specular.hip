@@ -50,27 +50,47 @@ __global__ __launch_bounds__(kBlock) void k_spec_spawn(DevScene s, rtg_view view
                                                         uint32_t max_depth, double *next_rays6, SpecMeta *next_meta,
                                                         uint32_t *groups, uint32_t *counters) {
     uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= n) return;
-    const rtg_point &pt = points[gid];
-    if (!refracts(s, pt)) return;
-    const DevMaterial &m = material_of_slot(s, pt.material_slot);
-    Ray ray;
-    SpecMeta me;
-    if (rays6) {
-        ray = load_ray6(rays6, gid);
-        me = meta[gid];
-    } else {
-        uint32_t py = (uint32_t)(gid / tile.w), px = (uint32_t)(gid - (uint64_t)py * tile.w);
-        ray = primary_ray(view, tile.x0 + px, tile.y0 + py, width, height);
-        me.group = atomicAdd(counters + 1, 1u);
+    const bool active = gid < n && refracts(s, points[gid]);
+    // The two counters are bumped once per wave: the lanes that spawn take consecutive places (a lane with a
+    // refracted ray takes two), in lane order.
+    const uint64_t spawning = __ballot(active);
+    if (spawning == 0) return;
+    Ray ray{};
+    SpecMeta me{};
+    Dielectric di{};
+    V3 pos = mk(0.0, 0.0, 0.0);
+    if (active) {
+        const rtg_point &pt = points[gid];
+        const DevMaterial &m = material_of_slot(s, pt.material_slot);
+        if (rays6) {
+            ray = load_ray6(rays6, gid);
+            me = meta[gid];
+        } else {
+            uint32_t py = (uint32_t)(gid / tile.w), px = (uint32_t)(gid - (uint64_t)py * tile.w);
+            ray = primary_ray(view, tile.x0 + px, tile.y0 + py, width, height);
+        }
+        di = dielectric_new(ray.d, ld3(pt.geo_normal), m.n1, m.n2);
+        pos = ld3(pt.position);
+    }
+    const uint64_t twice = __ballot(active && di.has_refract);
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((unsigned long long)spawning) - 1;
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t ray_base = 0, group_base = 0;
+    if ((int)lane == leader) {
+        ray_base = atomicAdd(counters, (uint32_t)(__popcll(spawning) + __popcll(twice)));
+        if (!rays6) group_base = atomicAdd(counters + 1, (uint32_t)__popcll(spawning));
+    }
+    ray_base = __shfl(ray_base, leader, 64);
+    group_base = __shfl(group_base, leader, 64);
+    if (!active) return;
+    if (!rays6) {
+        me.group = group_base + (uint32_t)__popcll(spawning & below);
         me.slot = 0;
         me.attenuation = 1.0;
         groups[me.group] = (uint32_t)gid;
     }
-    Dielectric di = dielectric_new(ray.d, ld3(pt.geo_normal), m.n1, m.n2);
-    V3 pos = ld3(pt.position);
-    uint32_t n_out = di.has_refract ? 2u : 1u;
-    uint32_t at = atomicAdd(counters, n_out);
+    const uint32_t at = ray_base + (uint32_t)(__popcll(spawning & below) + __popcll(twice & below));
     // children of the node at `depth` with pre-order index `slot`: the reflected subtree comes first
     SpecMeta c;
     c.group = me.group;
