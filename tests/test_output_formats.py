@@ -48,6 +48,34 @@ def test_images_tar_holds_the_three_images():
         assert np.all((pq >= 0.0) & (pq <= 1.0))
 
 
+def test_large_images_encode_like_their_rows():
+    """Pictures above 65 536 pixels are encoded by several host threads (rows shared among them): the bytes equal
+    those of the same rows encoded one strip at a time, NaN pixels (the reference's checkerboard, render/image.rs:52-58)
+    included; the sizing calls agree with what is written."""
+    rng = np.random.default_rng(8)
+    w, h = 640, 411
+    rgb = rng.uniform(0.0, 3.0, size=(h, w, 3)) * rng.choice([1e-4, 1.0, 700.0], size=(h, w, 1))
+    rgb[rng.random((h, w)) < 0.01] = np.nan
+    rgb[5, 7] = 0.0
+    whole = rtg.to_hdr(rgb, w, h)
+    head, _, rest = whole.partition(b"\n\n")
+    pixels = rest.partition(b"\n")[2]
+    strips = b""
+    for y0 in range(0, h, 2):                      # two rows at a time keeps the checkerboard's parity
+        piece = rtg.to_hdr(np.ascontiguousarray(rgb[y0:y0 + 2]), w, min(2, h - y0))
+        strips += piece.partition(b"\n\n")[2].partition(b"\n")[2]
+    assert pixels == strips
+    blob = rtg.images_tar(rgb, w, h, seconds=1.25)
+    with tarfile.open(fileobj=io.BytesIO(blob)) as tar:
+        members = {m.name: m for m in tar.getmembers()}
+        assert tar.extractfile(members["image.hdr"]).read() == whole
+        pq = tar.extractfile(members["image.pq.hdr"]).read()
+    small = rtg.images_tar(np.ascontiguousarray(rgb[:2]), w, 2)
+    with tarfile.open(fileobj=io.BytesIO(small)) as tar:
+        pq_small = tar.extractfile("image.pq.hdr").read()
+    assert pq.partition(b"\n\n")[2].partition(b"\n")[2][: w * 2 * 4] == pq_small.partition(b"\n\n")[2].partition(b"\n")[2]
+
+
 def test_fibonacci_sphere_directions():
     """Sphere::fibonacci_sphere + ZenithY::into_normal (geo/sphere.rs:27-32,48-80): unit vectors, heights climbing
     from -1 to +1 in steps of dydi = 2 / (count + d), zenith advancing by the golden angle."""
