@@ -319,6 +319,75 @@ def test_caustic_term_through_meshes(gpu_ctx):
     assert np.array_equal(d_rgb.cpu().numpy().reshape(-1, 3), got)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_photon_paths_in_random_scenes(gpu_ctx, seed):
+    """Random scenes -- one to three glass objects (spheres and closed meshes, under random similarity or stretched
+    transforms, with various refractive indices), a diffuse floor (plane or mesh), two or three lights anywhere above
+    -- through the whole photon path: the photon pass bit for bit, nearest photons, and the caustic term at the
+    points the photons themselves landed on (so every combination of reflection and refraction that occurs gets its
+    Newton correction)."""
+    rng = np.random.default_rng(500 + seed)
+    objs, bvhs = [], {}
+    for i in range(int(rng.integers(1, 4))):
+        centre = rng.uniform(-0.5, 0.5, size=3) * [1.0, 0.3, 1.0] + [0.0, 0.1, 0.0]
+        radius = float(rng.uniform(0.1, 0.25))
+        m = np.eye(4)
+        if rng.random() < 0.5:
+            m[:3, :3] = np.diag(rng.uniform(0.7, 1.4, size=3))                      # stretched
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        m[:3, :3] = q @ m[:3, :3]
+        m[:3, 3] = rng.normal(scale=0.05, size=3)
+        xf = rtg.transform_from_forward(m) if rng.random() < 0.7 else None
+        glass = rtg.material((0.0, 0.0, 0.0), dielectric=(1.0, float(rng.choice([1.33, 1.5, 2.4]))))
+        if rng.random() < 0.5:
+            objs.append(rtg.sphere_object(tuple(centre), radius, glass, xf))
+        else:
+            objs.append(rtg.mesh_object(None, glass, xf))
+            bvhs[len(objs) - 1] = rtg.HostBvh(uv_sphere(tuple(centre), radius, n_lat=6, n_lon=9))
+    if rng.random() < 0.5:
+        objs.append(rtg.plane_object((0.0, -0.5, 0.0), (0.0, 0.0, -1.0), (-1.0, 0.0, 0.0), rtg.material((1, 1, 1)),
+                                     rtg.material((0.1, 0.1, 0.1))))
+    else:
+        tris, xform = scenes.terrain(10, 10, seed=seed)
+        objs.append(rtg.mesh_object(None, rtg.material((0.7, 0.6, 0.5)), xform))
+        bvhs[len(objs) - 1] = rtg.HostBvh(tris)
+    pair = scenes.Pair(gpu_ctx, objs, bvhs)
+    n_lights = int(rng.integers(2, 4))
+    lights = np.zeros(n_lights, dtype=rtg.LIGHT_DTYPE)
+    lights["position"] = rng.uniform(-1.0, 1.0, size=(n_lights, 3)) * [1.0, 0.3, 1.0] + [0.0, 1.2, 0.0]
+    lights["color"] = rng.uniform(10.0, 100.0, size=(n_lights, 3))
+    dirs = np.stack([rtg.fibonacci_zenith_y(60_000, seed=seed * 10 + l) for l in range(n_lights)])
+    got = pair.gpu.photons_emit(lights, dirs)
+    want = pair.cpu.photons_emit(lights, dirs)
+    _photon_fields_equal(got, want)
+    assert got.shape[0] > 1000                                # every seed's glass catches light
+    pm = pair.gpu.photon_map(lights, dirs)
+    assert pm.n == got.shape[0]
+    kd = orc.OracleKd(got["position"])
+    q = got["position"][:: max(1, got.shape[0] // 500)] + rng.normal(scale=1e-3, size=(got["position"][:: max(1, got.shape[0] // 500)].shape))
+    idx, dist = pm.nearest(q, 3)
+    oidx, odist = kd.nearest(q, 3)
+    assert np.array_equal(dist.view(np.uint64), odist.view(np.uint64))
+    # the caustic term where photons landed on the diffuse floor
+    floor = len(objs) - 1
+    on_floor = got[(got["n_bounces"] >= 1)]
+    take = on_floor["position"][rng.choice(on_floor.shape[0], min(800, on_floor.shape[0]), replace=False)]
+    pts = _surface_points(pair, take + rng.normal(scale=2e-4, size=take.shape) * [1, 0, 1], lift=0.02)
+    pts = pts[(pts["manifold_len"] > 0)]
+    last = np.where(pts["manifold_len"] == 2, pts["manifold"][:, 1], pts["manifold"][:, 0])
+    pts = np.ascontiguousarray(pts[last == floor])
+    assert pts.shape[0] > 100
+    g = pair.gpu.indirect_irrad(pm, pts)
+    w = pair.cpu.indirect_irrad(kd, got, pts)
+    lit_g, lit_w = g.sum(axis=1) > 0, w.sum(axis=1) > 0
+    assert (lit_g != lit_w).mean() < 0.01
+    both = lit_g & lit_w
+    assert both.sum() > 100
+    close = np.isclose(g[both], w[both], rtol=IRRAD_RTOL, atol=0.0).all(axis=1)
+    assert close.mean() > 0.98, (seed, close.mean())
+    pm.close()
+
+
 def test_frame_with_the_photon_term(gpu_ctx):
     """raytrace_pixel with photons (src/render/renderer.rs:266-283): pixels that no photon reaches are bit-identical
     to the photon-less frame and to the oracle; pixels in the caustic agree within IRRAD_RTOL."""
