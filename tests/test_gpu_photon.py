@@ -357,6 +357,10 @@ def test_photon_paths_in_random_scenes(gpu_ctx, seed):
     lights["position"] = rng.uniform(-1.0, 1.0, size=(n_lights, 3)) * [1.0, 0.3, 1.0] + [0.0, 1.2, 0.0]
     lights["color"] = rng.uniform(10.0, 100.0, size=(n_lights, 3))
     dirs = np.stack([rtg.fibonacci_zenith_y(60_000, seed=seed * 10 + l) for l in range(n_lights)])
+    for depth in (1, 2, 3):                                   # shallower path trees: fewer bounces per photon, none at depth 1
+        shallow = pair.gpu.photons_emit(lights, dirs[:, :5000], max_depth=depth)
+        _photon_fields_equal(shallow, pair.cpu.photons_emit(lights, dirs[:, :5000], max_depth=depth))
+        assert (shallow["n_bounces"] < depth).all()
     got = pair.gpu.photons_emit(lights, dirs)
     want = pair.cpu.photons_emit(lights, dirs)
     _photon_fields_equal(got, want)
