@@ -24,6 +24,18 @@ def test_rtg_exports_every_declared_symbol():
         assert hasattr(rtg.lib, n), f"librtg.so does not export {n}"
 
 
+def test_the_documented_rust_binding_names_every_entry_point():
+    """The `extern "C"` block a maintainer of the reference would paste declares exactly the
+    functions of include/rtg.h: an entry point added to the header must reach the binding too."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    bound = set(re.findall(r"\bfn\s+(rtg_\w+)\s*\(", block))
+    declared = set(_declared("include/rtg.h", "rtg_"))
+    assert declared - bound == set(), f"not in the Rust binding: {sorted(declared - bound)}"
+    assert bound - declared == set(), f"bound but not declared: {sorted(bound - declared)}"
+
+
 def test_host_library_exports_every_declared_symbol():
     for n in _declared("raytracer_amd/host/rt_host_c.h", "rth_"):
         assert hasattr(rtg.host, n), f"librt_host.so does not export {n}"
