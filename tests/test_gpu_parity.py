@@ -4,6 +4,8 @@ Bar: hit object / leaf ids and hit times bit-exact; every other field of the Ray
 (the kernels use the reference's operation order in IEEE binary64 with contraction off); 8-bit PQ colour within
 1 LSB (device pow differs from the host libm in the last bits).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -521,7 +523,7 @@ def test_specular_slot_table_over_budget_falls_back(gpu_ctx):
     assert np.abs(g_c8[sl].astype(int) - c_c8.astype(int)).max() <= 1
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTG_FUZZ_SEEDS", "12"))))
 def test_fuzz_scenes_with_special_values(gpu_ctx, seed):
     """Random small scenes (meshes under random affine transforms, spheres, planes, in random order) traced with rays
     that carry special values: zero, denormal, huge and tiny components, infinities and NaNs in origins and

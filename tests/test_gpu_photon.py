@@ -5,6 +5,8 @@ Bars: the photon pass and the nearest-photon search are bit-exact (ids, distance
 caustic term goes through sin / cos of the corrected direction, which the GPU's math library and the host's round
 differently in the last place, so it is compared within a relative 1e-7 (stated at each check); which points are lit
 at all must agree exactly."""
+import os
+
 import numpy as np
 import pytest
 
@@ -319,7 +321,7 @@ def test_caustic_term_through_meshes(gpu_ctx):
     assert np.array_equal(d_rgb.cpu().numpy().reshape(-1, 3), got)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTG_FUZZ_SEEDS", "6"))))
 def test_photon_paths_in_random_scenes(gpu_ctx, seed):
     """Random scenes -- one to three glass objects (spheres and closed meshes, under random similarity or stretched
     transforms, with various refractive indices), a diffuse floor (plane or mesh), two or three lights anywhere above
@@ -364,7 +366,9 @@ def test_photon_paths_in_random_scenes(gpu_ctx, seed):
     got = pair.gpu.photons_emit(lights, dirs)
     want = pair.cpu.photons_emit(lights, dirs)
     _photon_fields_equal(got, want)
-    assert got.shape[0] > 1000                                # every seed's glass catches light
+    if got.shape[0] <= 1000:                                  # the glass caught little light: nothing more to compare
+        assert seed >= 6                                      # (never so for the seeds that always run)
+        return
     pm = pair.gpu.photon_map(lights, dirs)
     assert pm.n == got.shape[0]
     kd = orc.OracleKd(got["position"])
@@ -380,13 +384,17 @@ def test_photon_paths_in_random_scenes(gpu_ctx, seed):
     pts = pts[(pts["manifold_len"] > 0)]
     last = np.where(pts["manifold_len"] == 2, pts["manifold"][:, 1], pts["manifold"][:, 0])
     pts = np.ascontiguousarray(pts[last == floor])
-    assert pts.shape[0] > 100
+    if pts.shape[0] <= 100:
+        assert seed >= 6
+        return
     g = pair.gpu.indirect_irrad(pm, pts)
     w = pair.cpu.indirect_irrad(kd, got, pts)
     lit_g, lit_w = g.sum(axis=1) > 0, w.sum(axis=1) > 0
     assert (lit_g != lit_w).mean() < 0.01
     both = lit_g & lit_w
-    assert both.sum() > 100
+    if both.sum() <= 100:
+        assert seed >= 6
+        return
     close = np.isclose(g[both], w[both], rtol=IRRAD_RTOL, atol=0.0).all(axis=1)
     assert close.mean() > 0.98, (seed, close.mean())
     pm.close()
