@@ -587,6 +587,65 @@ def test_device_f64_div_and_sqrt_are_correctly_rounded(gpu_ctx):
     del math
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTG_FUZZ_SEEDS", "8"))))
+def test_fuzz_shaded_frames(gpu_ctx, seed):
+    """Random scenes with refracting and opaque spheres, planes and meshes under random transforms, one to three
+    lights anywhere (inside objects too), a random view and a random depth of the path tree: the frame -- primary
+    hits, direct light with its shadow rays, the specular tree -- must be the recursion's radiance bit for bit, over
+    the whole frame and over a ragged tile, for every traversal."""
+    rng = np.random.default_rng(9000 + seed)
+    objs, meshes = [], {}
+    for i in range(int(rng.integers(1, 7))):
+        kind = rng.integers(0, 3)
+        m = np.eye(4)
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        m[:3, :3] = q @ np.diag(rng.uniform(0.5, 1.6, size=3)) if rng.random() < 0.5 else q * rng.uniform(0.5, 1.5)
+        m[:3, 3] = rng.normal(scale=0.2, size=3)
+        xf = rtg.transform_from_forward(m) if rng.random() < 0.6 else None
+        glass = rng.random() < 0.4
+        mat = rtg.material(tuple(rng.uniform(0.0, 1.0, size=3)),
+                           dielectric=(1.0, float(rng.choice([1.1, 1.33, 1.5, 2.4]))) if glass else None)
+        centre = rng.uniform(-0.6, 0.6, size=3) + [0.0, 0.0, -0.6]
+        if kind == 0:
+            if rng.random() < 0.5:
+                tris, _ = scenes.terrain(int(rng.integers(3, 14)), int(rng.integers(3, 14)), seed=seed * 7 + i, local_scale=1.0)
+                tris = tris * rng.uniform(0.05, 0.2) + centre
+            else:
+                n = int(rng.integers(1, 200))
+                tris = centre + rng.normal(size=(n, 1, 3)) * 0.4 + rng.normal(size=(n, 3, 3)) * rng.choice([0.03, 0.2])
+            objs.append(rtg.mesh_object(None, mat, xf))
+            meshes[i] = rtg.HostBvh(np.ascontiguousarray(tris))
+        elif kind == 1:
+            objs.append(rtg.sphere_object(tuple(centre), float(rng.uniform(0.05, 0.4)), mat, xf))
+        else:
+            t1, t2 = rng.normal(size=3), rng.normal(size=3)
+            objs.append(rtg.plane_object(tuple(centre + [0.0, -0.6, 0.0]), tuple(t1), tuple(t2), mat,
+                                         rtg.material(tuple(rng.uniform(0.0, 1.0, size=3))), xf))
+    pair = scenes.Pair(gpu_ctx, objs, meshes)
+    lights = np.zeros(int(rng.integers(1, 4)), dtype=rtg.LIGHT_DTYPE)
+    lights["position"] = rng.uniform(-1.5, 1.5, size=(lights.shape[0], 3))
+    lights["color"] = rng.uniform(0.0, 200.0, size=(lights.shape[0], 3))
+    view = rtg.make_view(orig=tuple(rng.normal(scale=0.3, size=3) + [0.0, 0.0, 1.0]), fov=(float(rng.uniform(0.5, 2.5)), float(rng.uniform(0.5, 2.5))))
+    w, h = int(rng.integers(17, 120)), int(rng.integers(17, 90))
+    max_depth = int(rng.integers(1, 6))
+    tile = (int(rng.integers(0, w // 2)), int(rng.integers(0, h // 2)), int(rng.integers(1, w // 2)), int(rng.integers(1, h // 2)))
+    c_rgb, c_c8, c_hits = pair.cpu.render_frame(view, lights, w, h, max_depth=max_depth)
+    t_rgb, t_c8, t_hits = pair.cpu.render_frame(view, lights, w, h, tile=tile, max_depth=max_depth)
+    if os.environ.get("RTG_FUZZ_VERBOSE"):
+        print(f"seed {seed}: {len(objs)} objects {w}x{h} depth {max_depth} hit {float((c_hits['object'] != rtg.RTG_NONE).mean()):.2f} "
+              f"lit {float((c_rgb.sum(axis=1) > 0).mean()):.2f} objects seen {np.unique(c_hits['object']).tolist()}")
+    for traversal in TRAVERSALS:
+        gpu_ctx.set_option("traversal", traversal)
+        g_rgb, g_c8, g_hits = pair.gpu.render_frame(view, lights, w, h, max_depth=max_depth)
+        _assert_hits_equal(g_hits, c_hits)
+        assert not scenes.float_bits_differ(g_rgb, c_rgb).any(), (seed, traversal)
+        assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1
+        g_rgb, g_c8, g_hits = pair.gpu.render_frame(view, lights, w, h, tile=tile, max_depth=max_depth)
+        _assert_hits_equal(g_hits, t_hits)
+        assert not scenes.float_bits_differ(g_rgb, t_rgb).any(), (seed, traversal, "tile")
+    gpu_ctx.set_option("traversal", 2)
+
+
 @pytest.mark.parametrize("family", [0, 1, 2, 3])
 def test_reciprocal_quotient_equals_ieee_division(gpu_ctx, family):
     """The phased kernel's box test replaces x/d by two FMA refinements of x*(1/d); every bit must agree with the
