@@ -397,6 +397,17 @@ def test_photon_paths_in_random_scenes(gpu_ctx, seed):
         return
     close = np.isclose(g[both], w[both], rtol=IRRAD_RTOL, atol=0.0).all(axis=1)
     assert close.mean() > 0.98, (seed, close.mean())
+    # a small frame from above with the photon term: the plain frame where no photon counts, the oracle's caustic elsewhere
+    view = rtg.make_view(orig=(0.0, 0.3, 1.6), fov=(1.2, 1.0))
+    fw, fh = 56, 40
+    f_got, _ = pair.gpu.render_frame_photons(view, lights, pm, fw, fh, rgba8=False)
+    f_want, _ = pair.cpu.render_frame_photons(view, lights, kd, got, fw, fh)
+    f_plain, _, _ = pair.gpu.render_frame(view, lights, fw, fh, hits=False)
+    caustic = (f_want != f_plain).any(axis=1)
+    assert not scenes.float_bits_differ(f_got[~caustic], f_plain[~caustic]).any()
+    if caustic.sum() > 20:
+        ok = np.isclose(f_got[caustic], f_want[caustic], rtol=IRRAD_RTOL, atol=1e-300).all(axis=1)
+        assert ok.mean() > 0.97, (seed, ok.mean(), int(caustic.sum()))
     pm.close()
 
 
