@@ -1,6 +1,8 @@
 """Trispline patches (src/trispline.rs): the conversion chain and evaluation are pinned by the reference's formulas;
 ray/patch intersection does not exist in the reference, so it is this build's definition (see rtg_patch_set in
 include/rtg.h) -- "parity unpinned" against the reference, oracle-vs-GPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -128,6 +130,37 @@ def test_gpu_patch_scene_matches_oracle(gpu_ctx, traversal):
     c_rgb, c_c8, _ = pair.cpu.render_frame(view, lights, w, h, max_depth=3)
     assert not scenes.float_bits_differ(g_rgb, c_rgb).any()
     assert np.abs(g_c8.astype(int) - c_c8.astype(int)).max() <= 1
+    gpu_ctx.set_option("traversal", 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTG_FUZZ_SEEDS", "4"))))
+def test_fuzz_patch_scenes(gpu_ctx, seed):
+    """Random patch terrains (size, tessellation, Newton steps, placement), with or without the default sphere and
+    floor around them, seen from random views: hits, points and visit counters of every traversal, and the shaded
+    frame, against the oracle bit for bit."""
+    rng = np.random.default_rng(7000 + seed)
+    patches = rtg.patch_terrain(int(rng.integers(2, 20)), int(rng.integers(2, 14)), seed=int(rng.integers(1 << 20)), scale=100.0)
+    pm = rtg.HostPatchMesh(patches, k=int(rng.choice([1, 2, 3, 4, 6])), newton_steps=int(rng.integers(1, 8)))
+    with_default = bool(rng.random() < 0.5)
+    xf = rtg.transform(float(rng.uniform(0.005, 0.02)), tuple(rng.normal(scale=0.1, size=3)))
+    objs, lights, view = scenes.patch_scene_objects(xf, time=int(rng.integers(0, 100)), with_default=with_default)
+    pair = scenes.Pair(gpu_ctx, objs, {(2 if with_default else 0): pm})
+    view = rtg.make_view(orig=tuple(rng.normal(scale=0.2, size=3) + [0.0, 0.2, 1.0]), fov=(float(rng.uniform(0.8, 2.2)), float(rng.uniform(0.8, 2.2))))
+    w, h = int(rng.integers(20, 200)), int(rng.integers(20, 140))
+    c_hits, c_pts, c_ctr = pair.cpu.render_primary(view, w, h, points=True, counters=True)
+    c_rgb, c_c8, _ = pair.cpu.render_frame(view, lights, w, h, max_depth=3)
+    for traversal in (0, 1, 2):
+        gpu_ctx.set_option("traversal", traversal)
+        g_hits, g_pts, g_ctr = pair.gpu.render_primary(view, w, h, points=True, counters=True)
+        assert scenes.hit_mismatches(g_hits, c_hits).size == 0, (seed, traversal)
+        for name in rtg.POINT_DTYPE.names:
+            a, b = g_pts[name], c_pts[name]
+            diff = scenes.float_bits_differ(a, b) if a.dtype.kind == "f" else (a != b)
+            assert not diff.any(), (seed, traversal, name)
+        assert np.array_equal(g_ctr, c_ctr), (seed, traversal)
+        g_rgb, g_c8, _ = pair.gpu.render_frame(view, lights, w, h, max_depth=3)
+        assert not scenes.float_bits_differ(g_rgb, c_rgb).any(), (seed, traversal)
     gpu_ctx.set_option("traversal", 2)
 
 
