@@ -1,0 +1,61 @@
+"""GPU: handles give back what they took.  Contexts, meshes (host-flattened and device-built), scenes, photon maps and
+communicators are created, used and destroyed over and over; the device memory in use afterwards is what it was
+before (the reference leans on Rust's ownership for this: `Arc<Bvh>`, `Renderer` dropping its `KdTree`)."""
+import numpy as np
+import pytest
+
+import scenes
+from raytracer_amd import rtg
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_bytes():
+    import torch
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
+def _one_round(tris, rays, lights, dirs, view):
+    ctx = rtg.Context(0)
+    host = rtg.HostBvh(tris)
+    flattened = ctx.mesh(host)
+    built = ctx.build_mesh(tris)
+    glass = rtg.sphere_object((0.0, 0.1, 0.0), 0.2, rtg.material((0.0, 0.0, 0.0), dielectric=(1.0, 1.5)))
+    scene = ctx.scene([glass, rtg.mesh_object(flattened, rtg.material((0.5, 0.5, 0.5)), rtg.transform(0.01)),
+                       rtg.mesh_object(built, rtg.material((0.5, 0.5, 0.5)), rtg.transform(0.01, (0.0, -0.3, 0.0)))])
+    scene.render_primary(view, 160, 120, points=True, counters=True)
+    scene.trace(rays, points=True)
+    scene.render_frame(view, lights, 96, 64)
+    scene.trace_paths(rays[:2000])
+    pm = scene.photon_map(lights, dirs)
+    scene.render_frame_photons(view, lights, pm, 64, 48)
+    photons = scene.photons_emit(lights, dirs)
+    pm2 = rtg.PhotonMap(ctx, photons)
+    pm2.nearest(photons["position"][:100], 3)
+    comm = rtg.Comm(ctx)
+    with pytest.raises(rtg.RtgError):                      # a failing call in the middle must not strand anything either
+        scene.photons_emit(lights, dirs, capacity=1)
+    comm.close()
+    pm2.close()
+    pm.close()
+    scene.close()
+    built.close()
+    flattened.close()
+    host.close()
+    ctx.close()
+
+
+def test_create_use_destroy_leaves_no_device_memory_behind():
+    tris, _ = scenes.terrain(40, 30, seed=2)
+    rng = np.random.default_rng(3)
+    rays = np.concatenate([rng.uniform(-1, 1, size=(20000, 3)) + [0, 0.5, 0], rng.normal(size=(20000, 3))], axis=1)
+    _, lights, view = scenes.default_objects(0)
+    lights = np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
+    dirs = np.stack([rtg.fibonacci_zenith_y(20_000, seed=l + 1) for l in range(2)])
+    _one_round(tris, rays, lights, dirs, view)             # first use: the runtime's own one-time allocations
+    before = _free_bytes()
+    for _ in range(12):
+        _one_round(tris, rays, lights, dirs, view)
+    after = _free_bytes()
+    assert before - after < 32 * 1024 * 1024, f"{(before - after) / 1e6:.1f} MB of device memory not returned after 12 rounds"
