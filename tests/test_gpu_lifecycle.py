@@ -1,6 +1,7 @@
 """GPU: handles give back what they took.  Contexts, meshes (host-flattened and device-built), scenes, photon maps and
 communicators are created, used and destroyed over and over; the device memory in use afterwards is what it was
-before (the reference leans on Rust's ownership for this: `Arc<Bvh>`, `Renderer` dropping its `KdTree`)."""
+before, and the process has not grown (the reference leans on Rust's ownership for this: `Arc<Bvh>`, `Renderer`
+dropping its `KdTree`)."""
 import numpy as np
 import pytest
 
@@ -53,9 +54,15 @@ def test_create_use_destroy_leaves_no_device_memory_behind():
     _, lights, view = scenes.default_objects(0)
     lights = np.ascontiguousarray(lights, dtype=rtg.LIGHT_DTYPE)
     dirs = np.stack([rtg.fibonacci_zenith_y(20_000, seed=l + 1) for l in range(2)])
-    _one_round(tris, rays, lights, dirs, view)             # first use: the runtime's own one-time allocations
-    before = _free_bytes()
+    import gc
+    import psutil
+    for _ in range(2):                                     # first uses: the runtime's own one-time allocations
+        _one_round(tris, rays, lights, dirs, view)
+    gc.collect()
+    before, host_before = _free_bytes(), psutil.Process().memory_info().rss
     for _ in range(12):
         _one_round(tris, rays, lights, dirs, view)
-    after = _free_bytes()
+    gc.collect()
+    after, host_after = _free_bytes(), psutil.Process().memory_info().rss
     assert before - after < 32 * 1024 * 1024, f"{(before - after) / 1e6:.1f} MB of device memory not returned after 12 rounds"
+    assert host_after - host_before < 256 * 1024 * 1024, f"host memory grew by {(host_after - host_before) / 1e6:.1f} MB over 12 rounds"
