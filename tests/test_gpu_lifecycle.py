@@ -66,3 +66,46 @@ def test_create_use_destroy_leaves_no_device_memory_behind():
     after, host_after = _free_bytes(), psutil.Process().memory_info().rss
     assert before - after < 32 * 1024 * 1024, f"{(before - after) / 1e6:.1f} MB of device memory not returned after 12 rounds"
     assert host_after - host_before < 256 * 1024 * 1024, f"host memory grew by {(host_after - host_before) / 1e6:.1f} MB over 12 rounds"
+
+
+def test_two_contexts_driven_from_two_host_threads():
+    """Distinct contexts may be driven from distinct host threads (include/rtg.h): two threads, each with its own
+    context and scene over one shared mesh, render different frames at the same time; every frame equals the one a
+    single thread renders."""
+    import threading
+    tris, xform = scenes.terrain(60, 45, seed=4)
+    host = rtg.HostBvh(tris)
+    main = rtg.Context(0)
+    mesh = main.mesh(host)
+    obj = rtg.mesh_object(mesh, rtg.material((0.5, 0.5, 0.5)), xform)
+    views = [rtg.make_view(orig=(0.1 * i - 0.4, 0.2, 1.0 + 0.05 * i)) for i in range(8)]
+    lights = np.ascontiguousarray(scenes.default_objects(3)[1], dtype=rtg.LIGHT_DTYPE)
+    w, h = 320, 200
+    scene = main.scene([obj])
+    want = [(scene.render_primary(v, w, h)[0], scene.render_frame(v, lights, w, h)[0]) for v in views]
+    failures = []
+
+    def worker(which):
+        try:
+            ctx = rtg.Context(0)
+            sc = ctx.scene([obj])
+            for _ in range(6):
+                for i in range(which, len(views), 2):
+                    hits = sc.render_primary(views[i], w, h)[0]
+                    rgb = sc.render_frame(views[i], lights, w, h)[0]
+                    if hits.tobytes() != want[i][0].tobytes() or scenes.float_bits_differ(rgb, want[i][1]).any():
+                        failures.append((which, i))
+            sc.close()
+            ctx.close()
+        except Exception as e:                                # noqa: BLE001 -- reported by the assertion below
+            failures.append((which, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert failures == []
+    scene.close()
+    mesh.close()
+    main.close()
