@@ -469,3 +469,29 @@ def test_renderer_with_its_photon_pass(gpu_ctx):
     assert close.mean() > 0.99, close.mean()
     assert all(x >= 0.0 for x in seconds)
 
+
+def test_plain_c_caller_renders_the_default_frame(gpu_ctx, tmp_path):
+    """examples/default_scene.c -- C11, include/rtg.h and librtg.so only -- renders the reference's default frame with
+    its photon pass; given the same directions, the Python harness gets the same doubles."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "default_scene")
+    assert os.path.exists(exe), "examples/default_scene is built by __graft_entry__.build()"
+    time, w, h, count = 11, 90, 70, 40_000
+    dirs = np.stack([rtg.fibonacci_zenith_y(count, seed=77 + l) for l in range(2)])
+    dirs_file, out_file = tmp_path / "dirs.f64", tmp_path / "frame.f64"
+    dirs.tofile(dirs_file)
+    done = subprocess.run([exe, str(w), str(h), str(count), str(time), str(out_file), str(dirs_file)], capture_output=True, text=True,
+                          timeout=120)
+    assert done.returncode == 0, done.stderr
+    assert "photons from 2 x 40000 directions" in done.stdout
+    got = np.fromfile(out_file, dtype=np.float64).reshape(-1, 3)
+    objs, lights, view = scenes.default_objects(time)
+    scene = gpu_ctx.scene(objs)
+    pm = scene.photon_map(_lights(lights), dirs)
+    want, _ = scene.render_frame_photons(view, _lights(lights), pm, w, h, rgba8=False)
+    plain, _, _ = scene.render_frame(view, _lights(lights), w, h, hits=False)
+    assert not scenes.float_bits_differ(got, want).any()
+    assert (want != plain).any(axis=1).sum() > 20             # the caustic is in the picture
+    pm.close()
+    scene.close()
+
