@@ -176,6 +176,9 @@ def main():
     ap.add_argument("--loopback", action="store_true",
                     help="with --force-dist on one rank: the gather goes through RCCL (the rank sends to itself) instead "
                          "of device copies, so RCCL's kernels run next to the traversal as they do with several ranks")
+    ap.add_argument("--fanin", type=int, default=1,
+                    help="with --force-dist --loopback: frames the rank receives from itself per step (8 = the root's load "
+                         "in an 8-GPU run)")
     ap.add_argument("--gather", choices=["native", "torch"], default="native",
                     help="native: rtg_gather_tiles behind the C ABI (RCCL send/recv); torch: torch.distributed.gather")
     args = ap.parse_args()
@@ -280,8 +283,16 @@ def main():
         else:
             gather_kind = "torch.distributed.gather"
         pieces = shard.frame_pieces(world, frame_bytes)
+        fanin = 1
+        if world == 1 and args.loopback and comm is not None and args.fanin > 1:
+            # rehearsal of the root's side of a gather from `fanin` ranks: the one rank sends its frame that many times
+            # to itself, into as many slots, through RCCL -- the receive traffic and the RCCL kernels of an N-GPU run
+            # next to the root's own traversal (the links themselves are what a single GPU cannot rehearse)
+            fanin = args.fanin
+            pieces = [(0, 0, k * frame_bytes, frame_bytes) for k in range(fanin)]
+            gather_kind += f", {fanin} frames received per step"
         if comm is not None:
-            recv = [[torch.empty(world * frame_bytes, dtype=torch.uint8, device=dev) if rank == 0 else None
+            recv = [[torch.empty(max(world, fanin) * frame_bytes, dtype=torch.uint8, device=dev) if rank == 0 else None
                      for _ in range(2)] for _ in range(inflight)]
         else:
             recv = [[[torch.empty_like(hits) for _ in range(world)] if rank == 0 else None for _ in range(2)]
