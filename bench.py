@@ -176,6 +176,9 @@ def main():
     ap.add_argument("--loopback", action="store_true",
                     help="with --force-dist on one rank: the gather goes through RCCL (the rank sends to itself) instead "
                          "of device copies, so RCCL's kernels run next to the traversal as they do with several ranks")
+    ap.add_argument("--hit-buffers", type=int, default=2,
+                    help="with a gather: hit buffers (and receive slots) per context, so a gather may lag the traversal by "
+                         "that many frames before it holds it up")
     ap.add_argument("--fanin", type=int, default=1,
                     help="with --force-dist --loopback: frames the rank receives from itself per step (8 = the root's load "
                          "in an 8-GPU run)")
@@ -247,15 +250,15 @@ def main():
     n_rays = WIDTH * HEIGHT
     tile = (0, 0, WIDTH, HEIGHT)
     frame_bytes = n_rays * 16
-    n_buf = 2 if use_dist else 1
+    n_buf = max(2, args.hit_buffers) if use_dist else 1      # hit buffers per context: a gather may lag that many frames
     hits_of = [[torch.empty(frame_bytes, dtype=torch.uint8, device=dev) for _ in range(n_buf)] for _ in range(inflight)]
     hits = hits_of[0][0]
     sizes = [hits.numel()] * world
     gather_kind = None
     if use_dist:
         comm_stream = torch.cuda.Stream(dev)          # gathers run here, traversal on the contexts' streams
-        rendered = [[torch.cuda.Event() for _ in range(2)] for _ in range(inflight)]
-        gathered = [[torch.cuda.Event() for _ in range(2)] for _ in range(inflight)]
+        rendered = [[torch.cuda.Event() for _ in range(n_buf)] for _ in range(inflight)]
+        gathered = [[torch.cuda.Event() for _ in range(n_buf)] for _ in range(inflight)]
         comm = None
         if args.gather == "native":
             # the library's own communicator: rank 0 makes the id, the others get it over the process group
@@ -293,15 +296,15 @@ def main():
             gather_kind += f", {fanin} frames received per step"
         if comm is not None:
             recv = [[torch.empty(max(world, fanin) * frame_bytes, dtype=torch.uint8, device=dev) if rank == 0 else None
-                     for _ in range(2)] for _ in range(inflight)]
+                     for _ in range(n_buf)] for _ in range(inflight)]
         else:
-            recv = [[[torch.empty_like(hits) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+            recv = [[[torch.empty_like(hits) for _ in range(world)] if rank == 0 else None for _ in range(n_buf)]
                     for _ in range(inflight)]
 
     def step(i, ev=None):
         frame = i * world + rank
         k = i % inflight                              # the context that takes this frame
-        b = (i // inflight) & 1 if use_dist else 0
+        b = (i // inflight) % n_buf if use_dist else 0
         st = streams[k]
         if use_dist:
             st.wait_event(gathered[k][b])             # the hit buffer is free once its previous gather has finished
