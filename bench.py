@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--hit-buffers", type=int, default=2,
                     help="with a gather: hit buffers (and receive slots) per context, so a gather may lag the traversal by "
                          "that many frames before it holds it up")
+    ap.add_argument("--root-in-place", choices=["auto", "on", "off"], default="auto",
+                    help="rank 0 traces its frames directly into the gathered buffer (auto: when N>1 and the gather is native)")
     ap.add_argument("--fanin", type=int, default=1,
                     help="with --force-dist --loopback: frames the rank receives from itself per step (8 = the root's load "
                          "in an 8-GPU run)")
@@ -300,6 +302,14 @@ def main():
         else:
             recv = [[[torch.empty_like(hits) for _ in range(world)] if rank == 0 else None for _ in range(n_buf)]
                     for _ in range(inflight)]
+        in_place = comm is not None and rank == 0 and fanin == 1 and (
+            args.root_in_place == "on" or (args.root_in_place == "auto" and world > 1))
+        if in_place:
+            # the root traces its own frames straight into its slot of the gathered buffer: the gather then has no
+            # copy to make for them (the library skips a piece whose source and destination are the same memory)
+            hits_of = [[recv[k][b][:frame_bytes] for b in range(n_buf)] for k in range(inflight)]
+            hits = hits_of[0][0]
+            gather_kind += ", the root's own frames traced in place"
 
     def step(i, ev=None):
         frame = i * world + rank

@@ -91,6 +91,20 @@ def test_one_rank_gather_through_rccl(gpu_ctx):
         st.synchronize()
         gpu_ctx.synchronize()
         assert recv.cpu().numpy().tobytes() == whole.cpu().numpy().tobytes()
+    # the root of a frame-mode run traces its own frame into slot 0 of the gathered buffer: that piece is in place
+    # (nothing is sent for it), the next slot arrives through RCCL
+    half = n // 2
+    slots = torch.full((n,), 0x5A, dtype=torch.uint8, device="cuda")
+    slots[:half] = whole[:half]
+    torch.cuda.synchronize()
+    comm.gather(0, slots.data_ptr(), slots.data_ptr(), [(0, 0, 0, half), (0, 0, half, half)])
+    gpu_ctx.synchronize()
+    first = whole[:half].cpu().numpy().tobytes()
+    assert slots.cpu().numpy().tobytes() == first + first
+    # all pieces in place: an empty group
+    comm.gather(0, slots.data_ptr(), slots.data_ptr(), [(0, 0, 0, n)])
+    gpu_ctx.synchronize()
+    assert slots.cpu().numpy().tobytes() == first + first
     comm.close()
     scene.close()
 
