@@ -12,7 +12,11 @@
  * or shading.  The oracle is pinned only by the reference's own unit tests
  * that touch the path (src/math/mat.rs:223-253 matrix inverses,
  * src/tree/bv_kd_tree.rs:80-95 union + surface area, src/geo/color.rs:19-30
- * PQ round trip) and by hand-derived known answers.
+ * PQ round trip) and by hand-derived known answers.  The one output the
+ * reference keeps of the path, saved/sphere.jpg (its default scene, photon
+ * term included), is a lossy picture: the oracle's frame of that scene agrees
+ * with it pixel for pixel in structure and in where the light falls
+ * (tests/test_oracle_picture.py), which no bit-exact claim can rest on.
  *
  * Data formats (rtg_bvh_node, rtg_tri, rtg_object, rtg_view, rtg_light,
  * rtg_hit, rtg_point, ...) are the PODs of include/rtg.h so the same buffers
