@@ -3,9 +3,8 @@
 tests/golden/reference_saved_sphere.jpg is a copy of the reference's saved/sphere.jpg: a 600x600 JPEG of the glass
 ball over the checker plane, photon term included, written by an earlier state of src/lib.rs whose two lights stood
 at (1, 1, 1) (blue) and (-1, 1, 1) (green) -- the values the commented-out lights of lib.rs:98-100 still show; the
-fit of the light position to the picture peaks there on all three axes.  The picture is lossy, its tone curve is not
-in the source and its photon directions were seeded from entropy, so nothing here is bit-exact: the measures below
-are independent of any monotone tone curve and insensitive to photon noise, and sharp enough that a ball 2.5 % larger,
+fit of the light position to the picture peaks there on all three axes.  The picture is lossy and its photon directions were seeded from entropy, so nothing
+here is bit-exact: the first measures below are independent of any monotone tone curve and insensitive to photon noise, and sharp enough that a ball 2.5 % larger,
 a refractive index of 1.45 instead of 1.5 or a frame shifted by one pixel fails them.
 """
 import os
@@ -64,6 +63,22 @@ def shading_agreement(ref, rgb, rgb8):
     rank = [float(stats.spearmanr(ref[FLOOR_ROW:, :, c].ravel()[::7], rgb[FLOOR_ROW:, :, c].ravel()[::7]).statistic)
             for c in (1, 2)]
     return chroma, rank[0], rank[1]
+
+
+def level_agreement(ref, rgb):
+    """The picture's levels are the linear radiance through the sRGB transfer curve at unit scale (found by fitting: no
+    other curve or scale comes close).  Returns the median absolute difference, in 8-bit levels, of the green and the
+    blue channel between the picture and the frame encoded that way, over the floor rows, both smoothed over 3x3
+    pixels.  An absolute check: the lights' intensity, the inverse-square and cosine factors, the two albedos of
+    the checker and the flux a photon carries all scale it."""
+    from scipy import ndimage as ndi
+    linear = np.clip(rgb, 0.0, 1.0)
+    encoded = 255.0 * np.where(linear <= 0.0031308, 12.92 * linear, 1.055 * linear ** (1.0 / 2.4) - 0.055)
+    out = []
+    for c in (1, 2):
+        d = ndi.uniform_filter(encoded[:, :, c], 3)[FLOOR_ROW:] - ndi.uniform_filter(ref[:, :, c], 3)[FLOOR_ROW:]
+        out.append(float(np.median(np.abs(d))))
+    return out[0], out[1]
 
 
 def lights_of_the_saved_picture(lights):

@@ -33,7 +33,10 @@ def test_default_scene_matches_the_saved_picture(gpu_ctx):
     assert chroma > 0.95 and green > 0.975 and blue > 0.955, (chroma, green, blue)
     whole, ball, _, _ = picture.structure_agreement(ref, c8)
     assert whole > 0.97 and ball > 0.965, (whole, ball)
+    level_green, level_blue = picture.level_agreement(ref, rgb)
+    assert level_green < 4.0 and level_blue < 5.0, (level_green, level_blue)
     print(f"saved picture: structure {whole:.4f} (ball {ball:.4f}), green-blue balance {chroma:.4f}, "
-          f"rank correlation green {green:.4f} blue {blue:.4f}, {photon_map.n} photons")
+          f"rank correlation green {green:.4f} blue {blue:.4f}, levels off by {level_green:.2f} / {level_blue:.2f} of 255 "
+          f"(median), {photon_map.n} photons")
     photon_map.close()
     scene.close()

@@ -73,6 +73,11 @@ def test_shading_of_the_saved_picture(ref):
     assert chroma > 0.95 and green > 0.975 and blue > 0.955, (chroma, green, blue)
     whole, ball, _, _ = picture.structure_agreement(ref, c8)
     assert whole > 0.955 and ball > 0.94, (whole, ball)
+    # absolute levels: within a few 8-bit steps of the picture; lights a fifth weaker are not
+    level_green, level_blue = picture.level_agreement(ref, rgb)
+    assert level_green < 4.0 and level_blue < 5.0, (level_green, level_blue)
+    dim_green, dim_blue = picture.level_agreement(ref, rgb * 0.8)
+    assert dim_green > 6.0 and dim_blue > 7.0, (dim_green, dim_blue)
     # controls: without the photon term, and with a light a tenth of a unit away, the same measures drop
     rgb0, c80 = _render(saved)
     chroma0, green0, blue0 = picture.shading_agreement(ref, rgb0, c80)
