@@ -72,13 +72,34 @@ def level_agreement(ref, rgb):
     pixels.  An absolute check: the lights' intensity, the inverse-square and cosine factors, the two albedos of
     the checker and the flux a photon carries all scale it."""
     from scipy import ndimage as ndi
-    linear = np.clip(rgb, 0.0, 1.0)
-    encoded = 255.0 * np.where(linear <= 0.0031308, 12.92 * linear, 1.055 * linear ** (1.0 / 2.4) - 0.055)
+    encoded = _srgb_levels(rgb)
     out = []
     for c in (1, 2):
         d = ndi.uniform_filter(encoded[:, :, c], 3)[FLOOR_ROW:] - ndi.uniform_filter(ref[:, :, c], 3)[FLOOR_ROW:]
         out.append(float(np.median(np.abs(d))))
     return out[0], out[1]
+
+
+def _srgb_levels(rgb):
+    linear = np.clip(rgb, 0.0, 1.0)
+    return 255.0 * np.where(linear <= 0.0031308, 12.92 * linear, 1.055 * linear ** (1.0 / 2.4) - 0.055)
+
+
+def photon_term_agreement(ref, rgb_direct, rgb):
+    """The photon term alone.  Inside the green light's shadow of the ball (direct green exactly zero in `rgb_direct`,
+    the frame without the photon term; floor only, away from the ball and from the shadow's edge) all the green of the
+    picture is light the ball focused there.  Returns the correlation and the median absolute difference in 8-bit
+    levels between the picture's green and the frame's (sRGB-encoded, both smoothed over 5x5 pixels), and the pixels
+    counted.  Green, because the picture's blue went through a colour conversion that its green did not (its red
+    channel is not zero either, the scene's is)."""
+    from scipy import ndimage as ndi
+    yy, xx = np.mgrid[0:SIZE, 0:SIZE]
+    region = (rgb_direct[:, :, 1] == 0) & (rgb_direct[:, :, 2] > 0) & (yy > FLOOR_ROW)
+    region &= (xx - BALL[0]) ** 2 + (yy - BALL[1]) ** 2 > (BALL[2] + 12) ** 2
+    region = ndi.binary_erosion(region, iterations=4)
+    a = ndi.uniform_filter(ref[:, :, 1], 5)[region]
+    b = ndi.uniform_filter(_srgb_levels(rgb)[:, :, 1], 5)[region]
+    return float(np.corrcoef(a, b)[0, 1]), float(np.median(np.abs(a - b))), int(region.sum())
 
 
 def lights_of_the_saved_picture(lights):

@@ -35,8 +35,11 @@ def test_default_scene_matches_the_saved_picture(gpu_ctx):
     assert whole > 0.97 and ball > 0.965, (whole, ball)
     level_green, level_blue = picture.level_agreement(ref, rgb)
     assert level_green < 4.0 and level_blue < 5.0, (level_green, level_blue)
+    direct, _, _ = scene.render_frame(view, saved, W, W)
+    corr, off, n = picture.photon_term_agreement(ref, direct.reshape(W, W, 3), rgb)
+    assert n > 15_000 and corr > 0.99 and off < 4.0, (corr, off, n)
     print(f"saved picture: structure {whole:.4f} (ball {ball:.4f}), green-blue balance {chroma:.4f}, "
           f"rank correlation green {green:.4f} blue {blue:.4f}, levels off by {level_green:.2f} / {level_blue:.2f} of 255 "
-          f"(median), {photon_map.n} photons")
+          f"(median), photon term alone: correlation {corr:.4f}, off by {off:.2f}, {photon_map.n} photons")
     photon_map.close()
     scene.close()

@@ -78,8 +78,14 @@ def test_shading_of_the_saved_picture(ref):
     assert level_green < 4.0 and level_blue < 5.0, (level_green, level_blue)
     dim_green, dim_blue = picture.level_agreement(ref, rgb * 0.8)
     assert dim_green > 6.0 and dim_blue > 7.0, (dim_green, dim_blue)
-    # controls: without the photon term, and with a light a tenth of a unit away, the same measures drop
+    # the photon term on its own, where no direct green light falls: right to a few levels; a quarter less flux is not
     rgb0, c80 = _render(saved)
+    corr, off, n = picture.photon_term_agreement(ref, rgb0, rgb)
+    assert n > 15_000 and corr > 0.99 and off < 4.0, (corr, off, n)
+    _, off_less, _ = picture.photon_term_agreement(ref, rgb0, rgb0 + 0.75 * (rgb - rgb0))
+    _, off_more, _ = picture.photon_term_agreement(ref, rgb0, rgb0 + 1.25 * (rgb - rgb0))
+    assert off_less > 6.0 and off_more > 6.0, (off_less, off_more)
+    # controls: without the photon term, and with a light a tenth of a unit away, the same measures drop
     chroma0, green0, blue0 = picture.shading_agreement(ref, rgb0, c80)
     assert green0 < green - 0.05 and blue0 < blue - 0.05, (green0, blue0)
     moved = saved.copy()
