@@ -25,8 +25,9 @@ def test_rtg_exports_every_declared_symbol():
 
 
 def test_the_documented_rust_binding_names_every_entry_point():
-    """The `extern "C"` block a maintainer of the reference would paste declares exactly the
-    functions of include/rtg.h: an entry point added to the header must reach the binding too."""
+    """The Rust `extern "C"` block a maintainer of the reference would paste (kept with the integration notes at the
+    repository root) declares exactly the functions of include/rtg.h: an entry point added to the header must reach
+    the binding too."""
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     block = text[text.index('extern "C" {'):]
     block = block[:block.index("\n}\n")]
