@@ -221,7 +221,7 @@ hipError_t build_kd_device(hipStream_t stream, const rtg_photon *photons, uint32
     const dim3 grid((n + 255) / 256), block(256);
     hipError_t e;
 
-    const uint32_t init[2] = {0u, 0xFFFFFFFFu};
+    static const uint32_t init[2] = {0u, 0xFFFFFFFFu};      // static: the copy below may read it after this call returns
     if ((e = hipMemcpyAsync(sum, init, sizeof(init), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     for (int axis = 0; axis < 3; axis++) {
         hipLaunchKernelGGL(k_kd_axis_keys, grid, block, 0, stream, photons, n, axis, keys[0], order[0], sum);
