@@ -4,7 +4,8 @@
  *
  *   default_scene <width> <height> <directions per light> <time> <out.f64> [<directions.f64>]
  *
- * writes width x height x 3 doubles (the frame's radiosity, row-major) to <out.f64>.  The emission directions
+ * writes width x height x 3 doubles (the frame's radiosity, row-major) to <out.f64>; an output name ending in .ppm
+ * gets an 8-bit picture through the sRGB curve instead.  The emission directions
  * (`ZenithY` pairs, light by light) are read from <directions.f64> when given, otherwise drawn here from a small
  * generator (the reference seeds its own from entropy). */
 #include <math.h>
@@ -45,6 +46,13 @@ static void fibonacci_zenith_y(uint64_t count, uint64_t seed, double *dirs2) {
         dirs2[k * 2] = fmod(phi * i, 2.0 * pi);
         dirs2[k * 2 + 1] = -1.0 + dydi * i + dydj * j;
     }
+}
+
+static unsigned char srgb8(double linear) {
+    if (!(linear > 0.0)) return 0; /* negative, zero, NaN */
+    if (linear > 1.0) linear = 1.0;
+    const double v = linear <= 0.0031308 ? 12.92 * linear : 1.055 * pow(linear, 1.0 / 2.4) - 0.055;
+    return (unsigned char)(v * 255.0 + 0.5);
 }
 
 int main(int argc, char **argv) {
@@ -114,7 +122,18 @@ int main(int argc, char **argv) {
            (unsigned long long)count, t1 - t0, width, height, t2 - t1);
 
     FILE *out = fopen(argv[5], "wb");
-    if (!out || fwrite(rgb, sizeof(double), (size_t)width * height * 3, out) != (size_t)width * height * 3) return fail(ctx, "writing the frame", -1);
+    const size_t values = (size_t)width * height * 3, name_len = strlen(argv[5]);
+    if (!out) return fail(ctx, "opening the output", -1);
+    if (name_len > 4 && strcmp(argv[5] + name_len - 4, ".ppm") == 0) {
+        unsigned char *bytes = malloc(values);
+        if (!bytes) return fail(ctx, "malloc", -3);
+        for (size_t k = 0; k < values; k++) bytes[k] = srgb8(rgb[k]);
+        fprintf(out, "P6\n%u %u\n255\n", width, height);
+        if (fwrite(bytes, 1, values, out) != values) return fail(ctx, "writing the picture", -1);
+        free(bytes);
+    } else if (fwrite(rgb, sizeof(double), values, out) != values) {
+        return fail(ctx, "writing the frame", -1);
+    }
     fclose(out);
     rtg_photon_map_destroy(map);
     rtg_scene_destroy(scene);

@@ -493,6 +493,18 @@ def test_plain_c_caller_renders_the_default_frame(gpu_ctx, tmp_path):
     plain, _, _ = scene.render_frame(view, _lights(lights), w, h, hits=False)
     assert not scenes.float_bits_differ(got, want).any()
     assert (want != plain).any(axis=1).sum() > 20             # the caustic is in the picture
+    # an output name ending in .ppm gets the same frame as an 8-bit picture through the sRGB curve
+    ppm_file = tmp_path / "frame.ppm"
+    done = subprocess.run([exe, str(w), str(h), str(count), str(time), str(ppm_file), str(dirs_file)], capture_output=True, text=True,
+                          timeout=120)
+    assert done.returncode == 0, done.stderr
+    raw = ppm_file.read_bytes()
+    header = b"P6\n%d %d\n255\n" % (w, h)
+    assert raw.startswith(header) and len(raw) == len(header) + w * h * 3
+    linear = np.clip(want, 0.0, 1.0)
+    levels = np.where(linear <= 0.0031308, 12.92 * linear, 1.055 * linear ** (1.0 / 2.4) - 0.055) * 255.0
+    picture = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(-1, 3).astype(np.float64)
+    assert np.abs(picture - levels).max() <= 0.5 + 1e-6
     pm.close()
     scene.close()
 
