@@ -526,7 +526,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                                                           rtg_hit *out_hits, rtg_ray_counters *out_counters,
                                                           const rtg_hit *__restrict__ prim_best) {
     uint32_t st_iter = 0, st_node = 0, st_node_l = 0, st_tri = 0, st_tri_l = 0, st_obj = 0, st_obj_l = 0, st_refill = 0;
-    uint32_t st_amb = 0, st_amb_l = 0;
+    uint32_t st_amb = 0, st_amb_l = 0, st_lines = 0;
     uint64_t tk_node = 0, tk_tri = 0, tk_obj = 0, tk_all = 0, tk0 = 0, tk1 = 0;
     if (STATS) tk_all = __builtin_amdgcn_s_memtime();
     WorkQueue wq;
@@ -861,6 +861,15 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
             if (STATS) {
                 st_node++;
                 st_node_l += (uint32_t)__popcll(m_node);
+                // different 128-byte lines the step's node load touches (hot node i sits at byte 64 + 32 i of the slab;
+                // lanes without a node read the root's record)
+                const uint32_t line = lanes_of(m_node) ? (cur + 2u) >> 2 : 0u;
+                uint64_t rest = ~0ull;
+                while (rest != 0) {
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)line, __ffsll((unsigned long long)rest) - 1);
+                    rest &= ~wave_ballot(line == v);
+                    st_lines++;
+                }
                 tk0 = __builtin_amdgcn_s_memtime();
             }
             // Lane sets are kept as scalar masks and combined with scalar instructions: a vote over a boolean that is
@@ -1075,6 +1084,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
         atomicAdd(st + 12, (uint32_t)(tk_tri >> 6));
         atomicAdd(st + 13, (uint32_t)(tk_obj >> 6));
         atomicAdd(st + 14, (uint32_t)(tk1 >> 6));
+        atomicAdd(st + 15, st_lines);
     }
 }
 

@@ -464,7 +464,7 @@ class Context:
         self._check(lib.rtg_ctx_debug_stats(self._h, out))
         names = ["iterations", "node_steps", "node_lanes", "tri_steps", "tri_lanes", "obj_steps", "obj_lanes",
                  "refills", "waves", "ambiguous_steps", "ambiguous_lanes", "node_ticks64", "tri_ticks64", "obj_ticks64",
-                 "wave_ticks64"]
+                 "wave_ticks64", "node_lines"]
         return dict(zip(names, list(out)))
 
     def mesh(self, bvh):

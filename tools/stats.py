@@ -21,4 +21,6 @@ scene.render_primary_raw(bench.frame_view(rtg, 0), bench.WIDTH, bench.HEIGHT, (0
 st = ctx.debug_stats()
 w = st["waves"]
 print(opts, {k: round(v / w, 1) for k, v in st.items()},
-      "node lanes/step %.1f tri lanes/step %.1f obj lanes/step %.1f" % (st["node_lanes"] / max(1, st["node_steps"]), st["tri_lanes"] / max(1, st["tri_steps"]), st["obj_lanes"] / max(1, st["obj_steps"])))
+      "node lanes/step %.1f tri lanes/step %.1f obj lanes/step %.1f, different 128-byte lines per node load %.1f" % (
+          st["node_lanes"] / max(1, st["node_steps"]), st["tri_lanes"] / max(1, st["tri_steps"]),
+          st["obj_lanes"] / max(1, st["obj_steps"]), st["node_lines"] / max(1, st["node_steps"])))
