@@ -856,6 +856,10 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
         for (int round = 0; round < RTG_ROUNDS; round++) {
         // ---- one box test per lane, repeated until a triangle step is due ----------------------
         uint64_t m_done_burst = 0;       // during a burst the lanes' phases live in the masks; written back after it
+        // A node step is a load, a wait and some thirty instructions that end in the next load; a triangle step is a
+        // long stretch of arithmetic.  The wave is latency-bound, so its node steps go ahead of other waves'
+        // triangle steps on the SIMD: the next load is out sooner (+2 % on the 1080p frame, nothing lost elsewhere).
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
         for (int rep = 0; rep < RTG_NODE_BURST && m_node != 0; rep++) {
             if (STATS) {
@@ -969,6 +973,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
             // go round again until a triangle step is due (finished lanes wait for the end of the burst)
             if ((uint32_t)__popcll(m_tri) >= tri_thr) break;
         }
+        __builtin_amdgcn_s_setprio(0);
         phase = lanes_of(m_tri) ? PH_TRI : (lanes_of(m_done_burst) ? PH_DONE : phase);
 
         // ---- one triangle per waiting lane ----------------------------------------------
