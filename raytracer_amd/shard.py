@@ -11,6 +11,9 @@ Two partitions are offered:
 * frame mode  -- frame f is rendered by rank f mod world (weak scaling: a sequence renders `world` frames at once);
 * tile mode   -- one frame is cut into horizontal strips of whole 8-row wave tiles, dealt round-robin
                  (`interleave` strips per rank) so sky-heavy and geometry-heavy rows are spread evenly.
+
+A batch of arbitrary rays (the reference's `bench_mesh`, src/tree/benchmark.rs:15-27, shadow or photon rays) is cut
+into contiguous ranges of whole 64-ray wave chunks, one per rank; the hit records land at their rays' positions.
 """
 from typing import List, Sequence, Tuple
 
@@ -69,6 +72,30 @@ def strip_pieces(plan: Sequence[Sequence[Rect]], width: int, pixel_bytes: int):
 def frame_pieces(world: int, frame_bytes: int, live=None):
     """Piece list of frame mode: rank r's finished frame lands in slot r of the root's receive buffer."""
     return [(r, 0, r * frame_bytes, frame_bytes) for r in range(world) if live is None or live[r]]
+
+
+def ray_ranges(n_rays: int, world: int, chunk: int = 64) -> List[Tuple[int, int]]:
+    """Per-rank [begin, end) of a ray batch: contiguous, in rank order, every boundary but the last a multiple of
+    `chunk` (a wave takes 64 consecutive rays), sizes differing by less than two chunks.  Ranks beyond the batch get an
+    empty range."""
+    if world <= 0:
+        raise ValueError("world must be positive")
+    if n_rays < 0:
+        raise ValueError("negative ray count")
+    n_chunks = (n_rays + chunk - 1) // chunk
+    out, begin = [], 0
+    for r in range(world):
+        end = min(n_rays, begin + (n_chunks // world + (1 if r < n_chunks % world else 0)) * chunk)
+        out.append((begin, end))
+        begin = end
+    assert begin == n_rays
+    return out
+
+
+def ray_pieces(ranges: Sequence[Tuple[int, int]], record_bytes: int):
+    """Piece list of a sharded ray batch: rank r's records (from the start of its send buffer) land at its rays'
+    positions in the root's receive buffer."""
+    return [(r, 0, b * record_bytes, (e - b) * record_bytes) for r, (b, e) in enumerate(ranges) if e > b]
 
 
 def gather_to_root(local: torch.Tensor, sizes: Sequence[int], dst: int = 0, group=None, out=None):
@@ -181,4 +208,26 @@ def render_sequence_frames(render_frame, n_frames: int, frame_elems: int, dtype,
             for r in range(world):
                 if live[r]:
                     out[base + r] = slots[r].clone()
+    return out
+
+
+def trace_rays_sharded(trace, n_rays: int, record_elems: int, dtype, device, dst: int = 0, group=None, gather=None):
+    """Batch mode: this rank traces its contiguous range with `trace(begin, end, out_flat_tensor)` (`record_elems`
+    elements of `dtype` per ray); one gather lands every range at its rays' positions on `dst`, which returns the
+    (n_rays, record_elems) records in ray order; other ranks return None.  `gather` as in render_frame_tiles."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ranges = ray_ranges(n_rays, world)
+    begin, end = ranges[rank]
+    local = torch.empty((end - begin) * record_elems, dtype=dtype, device=device)
+    if end > begin:
+        trace(begin, end, local)
+    pieces = ray_pieces(ranges, record_elems * local.element_size())
+    out = torch.empty((n_rays, record_elems), dtype=dtype, device=device) if rank == dst else None
+    send_b = local.view(torch.uint8)
+    recv_b = out.view(-1).view(torch.uint8) if out is not None else None
+    if gather is None:
+        gather_pieces(send_b, recv_b, pieces, dst, group)
+    else:
+        gather(send_b, recv_b, pieces)
     return out

@@ -108,3 +108,31 @@ def test_one_rank_gather_through_rccl(gpu_ctx):
     comm.close()
     scene.close()
 
+
+def test_ray_batch_ranges_assemble_in_ray_order(gpu_ctx):
+    """A batch of bench_mesh rays (src/tree/benchmark.rs:15-27) cut as for three ranks: every range traced on its own
+    from device memory into the send buffer, gathered by rtg_gather_tiles into a poisoned buffer -- the records of the
+    whole batch in ray order, equal to the oracle's."""
+    import torch
+    tris, xform = scenes.terrain(40, 40, seed=11)
+    bvh = rtg.HostBvh(tris)
+    objs, _, _ = scenes.mesh_scene_objects(xform, with_default=False)
+    pair = scenes.Pair(gpu_ctx, objs, {0: bvh})
+    n = 50_000                                     # 782 chunks of 64 rays: ranges of 261, 261 and 260 (ragged) chunks
+    rays = rtg.bench_mesh_rays((-1.2, -1.2, -1.2, 1.2, 1.2, 1.2), n)
+    d_rays = torch.from_numpy(rays).cuda()
+    ranges = shard.ray_ranges(n, 3)
+    assert ranges == [(0, 16704), (16704, 33408), (33408, 50000)]
+    send = torch.empty(n * 16, dtype=torch.uint8, device="cuda")
+    for b, e in ranges:
+        pair.gpu.trace_raw(d_rays.data_ptr() + b * 48, e - b, send.data_ptr() + b * 16)
+    # as one rank the three ranges sit back to back in the send buffer: the pieces of ray_pieces, re-based
+    pieces = [(0, ro, ro, nb) for _, _, ro, nb in shard.ray_pieces(ranges, 16)]
+    recv = torch.full((n * 16,), 0x5A, dtype=torch.uint8, device="cuda")
+    comm = rtg.Comm(gpu_ctx)
+    comm.gather(0, send.data_ptr(), recv.data_ptr(), pieces[::-1])
+    gpu_ctx.synchronize()
+    want, _, _ = pair.cpu.trace(rays)
+    assert recv.cpu().numpy().tobytes() == want.tobytes()
+    assert (want["leaf"] != 0xFFFFFFFF).sum() > 100
+    comm.close()

@@ -49,6 +49,23 @@ def test_piece_plans_tile_the_receive_buffer_once():
     assert shard.frame_pieces(3, 10, live=[True, False, True]) == [(0, 0, 0, 10), (2, 0, 20, 10)]
 
 
+def test_ray_ranges_cover_the_batch_once():
+    for n, world in [(0, 3), (1, 4), (63, 2), (64, 2), (65, 2), (1000, 3), (67108864, 8), (50000, 7), (130, 8)]:
+        ranges = shard.ray_ranges(n, world)
+        assert len(ranges) == world and ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))          # contiguous, in rank order
+        assert all((b % 64 == 0 or b == n) and (e % 64 == 0 or e == n) and b <= e for b, e in ranges)
+        sizes = [e - b for b, e in ranges]
+        assert max(sizes) - min(sizes) < 128
+        cover = np.zeros(n * 16, dtype=np.int32)
+        for r, so, ro, nb in shard.ray_pieces(ranges, 16):
+            assert so == 0 and nb == sizes[r] * 16 and ro == ranges[r][0] * 16
+            cover[ro:ro + nb] += 1
+        assert (cover == 1).all()
+    with pytest.raises(ValueError):
+        shard.ray_ranges(10, 0)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -131,6 +148,28 @@ def _worker_unequal(rank, world, port, result_path):
                                 for r in range(world))
                 ok = ok and all(torch.equal(eq_out[r], torch.full((4,), 10 * r + rnd, dtype=torch.int32))
                                 for r in range(world))
+        # a ray batch cut into contiguous ranges (the bench_mesh distribution): records in ray order on the root;
+        # 150 rays over 3 ranks leaves the last rank a ragged range, 100 rays over 3 ranks leaves it none
+        import orc
+        import scenes
+        from raytracer_amd import rtg
+        tris, xform = scenes.terrain(12, 12, seed=3)
+        objs, _, _ = scenes.mesh_scene_objects(xform, time=0)
+        pair = scenes.Pair(None, objs, {2: rtg.HostBvh(tris)})
+        for n in (150, 100, 0):
+            rays = rtg.bench_mesh_rays((-1.5, -1.5, -1.5, 1.5, 1.5, 1.5), n)
+
+            def trace(begin, end, out, rays=rays):
+                hits, _, _ = pair.cpu.trace(rays[begin:end], threads=1)
+                out.copy_(torch.from_numpy(np.frombuffer(hits.tobytes(), dtype=np.uint8).copy()))
+
+            got = shard.trace_rays_sharded(trace, n, 16, torch.uint8, "cpu")
+            if rank == 0:
+                full, _, _ = pair.cpu.trace(rays, threads=1)
+                ok = ok and got.shape == (n, 16) and got.numpy().tobytes() == full.tobytes()
+            else:
+                ok_other = got is None
+                assert ok_other
         if rank == 0:
             with open(result_path, "w") as fh:
                 fh.write(str(int(ok)))
