@@ -1,0 +1,61 @@
+"""CPU: the roofline of the committed bench record can be recomputed from the files under profiles/ alone -- the
+microbenchmark's lane-load rates and the counter means give the ceiling, the counter traffic gives the HBM figure,
+and bench.py's record follows from them with the launch duration and the visits per ray it states."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import bench  # noqa: E402
+import roofline_ceiling  # noqa: E402
+
+CASES = [("config2-1920x1080", 1920 * 1080, 0.0, 2097152, lambda rec: rec["roofline"]),
+         ("config4-64Mrays-10Mtris", 1 << 26, 48.0, 33554432, lambda rec: rec["configs"]["c4"]["roofline"])]
+
+
+def _record():
+    newest = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles"))
+                    if os.path.isfile(os.path.join(ROOT, "profiles", d, "bench.json")))[-1]
+    with open(os.path.join(ROOT, "profiles", newest, "bench.json")) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("workload,n_rays,ray_bytes,beyond,pick", CASES)
+def test_ceiling_follows_from_the_microbenchmark_and_the_counters(workload, n_rays, ray_bytes, beyond, pick):
+    c = bench.committed("ceiling.json", workload, "k_trace_phased")
+    assert c is not None
+    r1, r2, r3 = roofline_ceiling.gather_rates(os.path.join(ROOT, c["gather_lane_loads_per_s"]["source"]), beyond)
+    assert c["gather_lane_loads_per_s"]["beyond_l2_table_records"] == beyond
+    assert (r1, r2, r3) == pytest.approx((c["gather_lane_loads_per_s"]["l1"], c["gather_lane_loads_per_s"]["l2"],
+                                          c["gather_lane_loads_per_s"]["beyond_l2"]), rel=1e-9)
+    assert r1 > r2 > r3 > 0
+    k = roofline_ceiling.counters(os.path.join(ROOT, c["fractions"]["source"]))
+    to_l2 = k["TCP_TCC_READ_REQ_sum"] / k["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    past_l2 = to_l2 * k["TCC_MISS_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"])
+    f = c["fractions"]
+    assert (f["l1"], f["l2"], f["beyond_l2"]) == pytest.approx((1 - to_l2, to_l2 - past_l2, past_l2), abs=2e-5)
+    lane_loads = 1.0 / (f["l1"] / r1 + f["l2"] / r2 + f["beyond_l2"] / r3)
+    assert c["ceiling_visits_per_s"] == pytest.approx(lane_loads / c["loads_per_visit"], rel=1e-4)
+
+
+@pytest.mark.parametrize("workload,n_rays,ray_bytes,beyond,pick", CASES)
+def test_committed_bench_record_follows_from_the_committed_evidence(workload, n_rays, ray_bytes, beyond, pick):
+    roof = pick(_record())
+    again = bench.roofline_record("k_trace_phased", workload, roof["kernel_ms"], n_rays, roof["nodes_per_ray"],
+                                  roof["tris_per_ray"], ray_bytes, True)
+    for part in ("gather", "hbm"):
+        assert 0 < roof[part]["frac"] <= 1
+        assert again[part]["frac"] == pytest.approx(roof[part]["frac"], rel=2e-3)
+        assert again[part]["peak"] == pytest.approx(roof[part]["peak"], rel=1e-6)
+    assert roof["frac"] == max(roof["gather"]["frac"], roof["hbm"]["frac"]) and roof["frac"] <= 1
+    assert again["bound"] == roof["bound"]
+    # traffic: the counter bytes of the committed pass, corrected as the file says
+    t = bench.committed("traffic.json", workload, "k_trace_phased")
+    assert t["hbm_bytes_per_launch"] == pytest.approx(
+        (2 * t["fetch_size_kb_per_launch"] + t["write_size_kb_per_launch"]) * 1024, rel=1e-9)
+    assert roof["traffic"] == pytest.approx(t["hbm_bytes_per_launch"] / 1e9, rel=1e-3)

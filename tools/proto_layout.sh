@@ -1,6 +1,6 @@
 #!/bin/bash
 # Node-layout prototype: the shipped library against the -DRTG_PROTO_LINK build in its layouts.
-# Usage: tools/proto_layout.sh c2|c4 > gpurun_out/proto_layout_<what>.txt
+# Usage: tools/proto_layout.sh c2|c4 > gpurun_out/proto_layout_<what>.txt   (take build_ab out of .gpurunignore first)
 set -e
 what=$1
 timeout -k 10 200 python tools/proto_layout.py $what shipped
