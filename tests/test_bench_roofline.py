@@ -59,3 +59,20 @@ def test_committed_bench_record_follows_from_the_committed_evidence(workload, n_
     assert t["hbm_bytes_per_launch"] == pytest.approx(
         (2 * t["fetch_size_kb_per_launch"] + t["write_size_kb_per_launch"]) * 1024, rel=1e-9)
     assert roof["traffic"] == pytest.approx(t["hbm_bytes_per_launch"] / 1e9, rel=1e-3)
+
+
+def test_launch_duration_agrees_with_the_rocprofv3_summary_of_the_same_command():
+    """kernel_stats.csv is `rocprofv3 --kernel-trace --stats` over `python3 bench.py --no-cpu --no-c4`;
+    bench_under_rocprof.json is the line that very run printed.  The duration bench.py takes from the launches' own
+    events and the profiler's average over the same launches (warm-up included) agree within 2 %."""
+    import csv
+    d = os.path.join(ROOT, "profiles", "r2_3_final")
+    with open(os.path.join(d, "bench_under_rocprof.json")) as f:
+        rec = json.loads(f.read().strip().splitlines()[-1])
+    rows = [r for r in csv.DictReader(open(os.path.join(d, "kernel_stats.csv")))
+            if "k_trace_phased<rtg::PrimarySource, false" in r["Name"]]
+    assert len(rows) == 1
+    assert int(rows[0]["Calls"]) == rec["warmup"] + rec["steps"] * rec["windows"]
+    assert float(rows[0]["AverageNs"]) / 1e6 == pytest.approx(rec["roofline"]["kernel_ms"], rel=0.02)
+    # the dominant kernel: nearly all of the GPU time of the run
+    assert float(rows[0]["Percentage"]) > 95
