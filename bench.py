@@ -83,11 +83,14 @@ def committed(name, workload_key, kernel):
     return best
 
 
-def roofline_record(kernel, workload_key, kernel_ms, n_rays, nodes_per_ray, tris_per_ray, ray_in_bytes, use_committed):
+def roofline_record(kernel, workload_key, kernel_ms, n_rays, nodes_per_ray, tris_per_ray, ray_in_bytes, use_committed,
+                    tree=None):
     """The `roofline` object.  Two ceilings are priced -- `gather` (the rate at which the CUs' vector memory path
     serves the node fetches, per cache level) and `hbm` (counter traffic against HBM peak) -- and the top-level
     bound / achieved / peak / frac are those of the one that binds (the larger fraction).  `algorithmic` is the byte
-    rate the traversal asks for, for information."""
+    rate the traversal asks for, for information; `compulsory` (given `tree` = (nodes, leaves)) is the least a launch
+    could move: the scene as the kernel stores it, once (32-byte hot nodes, 80-byte triangle records), the rays in and
+    the hit records out."""
     seconds = kernel_ms * 1e-3
     bytes_per_ray = nodes_per_ray * 64.0 + tris_per_ray * 72.0 + ray_in_bytes + 16.0
     visits_per_s = nodes_per_ray * n_rays / seconds
@@ -113,6 +116,12 @@ def roofline_record(kernel, workload_key, kernel_ms, n_rays, nodes_per_ray, tris
                 "algorithmic": {"bytes_per_ray": round(bytes_per_ray, 1),
                                 "gbs": round(bytes_per_ray * n_rays / seconds / 1e9, 1),
                                 "note": "bytes the traversal asks for; mostly cache hits, not HBM traffic"}})
+    if tree is not None:
+        least = tree[0] * 32.0 + tree[1] * 80.0 + n_rays * (ray_in_bytes + 16.0)
+        rec["compulsory"] = {"bytes_per_launch": round(least / 1e9, 4), "unit": "GB",
+                             "traffic_over_compulsory": None if traffic is None else
+                             round(float(traffic["hbm_bytes_per_launch"]) / least, 2),
+                             "note": "scene once (32-byte hot nodes, 80-byte triangles) + rays in + hit records out"}
     return rec
 
 
@@ -152,7 +161,7 @@ def run_config4(rtg, torch, ctx, dev, launches=3):
            "value": round(C4_RAYS * launches / wall / 1e6, 1), "unit": "Mrays/s", "launches": launches,
            "ms_per_launch": round(wall / launches * 1e3, 3), "rays_hit": n_hit, "setup_s": round(setup_s, 2),
            "roofline": roofline_record("k_trace_phased", "config4-64Mrays-10Mtris", kernel_ms, C4_RAYS,
-                                       c[0] / C4_RAYS, c[1] / C4_RAYS, 48.0, True)}
+                                       c[0] / C4_RAYS, c[1] / C4_RAYS, 48.0, True, (n_nodes, n_leaves))}
     scene.close()
     mesh.close()
     return rec
@@ -417,7 +426,8 @@ def main():
 
         kernel = KERNEL_OF_TRAVERSAL[args.traversal]
         default_run = args.traversal < 0 and not args.opt and args.grid is None
-        roof = roofline_record(kernel, "config2-1920x1080", kernel_ms, n_rays, nodes_per_ray, tris_per_ray, 0.0, default_run)
+        roof = roofline_record(kernel, "config2-1920x1080", kernel_ms, n_rays, nodes_per_ray, tris_per_ray, 0.0, default_run,
+                               (bvh.n_nodes, 2 * nx * ny))
         roof["concurrent_launches"] = inflight
         # the same visits against the whole timed region: what the GPU sustains with `inflight` launches overlapping
         roof["gather"]["achieved_timed_region"] = round(nodes_per_ray * n_rays * args.steps / elapsed / 1e9, 2)
