@@ -239,15 +239,19 @@ template <class F> void parallel_ranges(size_t n, F f) { api_parallel_ranges(n, 
 
 // Walks the caller's tree from the root: checks every range, rejects shared or
 // cyclic nodes, and emits (a) the reference-order node array with a
-// "last sibling" flag per node and (b) the pre-order threaded array with skip
-// links.  Iterative, so arbitrarily deep trees do not overflow the host stack.
+// "last sibling" flag per node and (b) the threaded array with pass and skip
+// links (place_threaded below decides where the nodes sit; `troot_out` is the
+// root's position).  Iterative, so arbitrarily deep trees do not overflow the
+// host stack.
+void place_threaded(std::vector<DevNode> &thr_nodes, uint32_t &troot_out);
 int layout_tree(rtg_ctx *ctx, const rtg_bvh *bvh, std::vector<DevNode> &ref_nodes, std::vector<DevNode> &thr_nodes,
-                uint32_t &depth_out) {
+                uint32_t &depth_out, uint32_t &troot_out) {
     const uint64_t nn = bvh->n_nodes, nl = bvh->n_leaves;
     ref_nodes.assign((size_t)nn, DevNode{});
     thr_nodes.clear();
     thr_nodes.reserve((size_t)nn);
     depth_out = 0;
+    troot_out = 0;
     if (nn == 0) return RTG_OK;
     if (bvh->root >= nn) return fail(ctx, RTG_E_INVALID, "bvh root %u out of range (%llu nodes)", bvh->root, (unsigned long long)nn);
     std::atomic<uint64_t> bad_node(UINT64_MAX);
@@ -308,7 +312,53 @@ int layout_tree(rtg_ctx *ctx, const rtg_bvh *bvh, std::vector<DevNode> &ref_node
             stack.pop_back();
         }
     }
+    place_threaded(thr_nodes, troot_out);
     return RTG_OK;
+}
+
+// Takes the threaded nodes in pre-order (link = pre-order index of the node after the subtree) and gives every node
+// its position, its skip link and its pass link (DevNode::nchild) by position.  A tree in which no node has leaves
+// and children at once -- every tree the builders make -- is stored with the children of a node side by side, the
+// groups in depth-first order of their parents and the root last, so that pairs of siblings start at even positions
+// and share a 64-byte half line; any other tree stays in pre-order (a node with leaves goes on to its children only
+// after its leaves, which the kernels read from the full node).  The visit order is the same in every placement.
+void place_threaded(std::vector<DevNode> &thr_nodes, uint32_t &troot_out) {
+    const uint32_t n = (uint32_t)thr_nodes.size();
+    troot_out = 0;
+    if (n == 0) return;
+    bool pure = true;
+    for (uint32_t i = 0; i < n && pure; i++) pure = !(thr_nodes[i].leaf_count != 0 && i + 1 < thr_nodes[i].link);
+    if (!pure || n == 1) {
+        for (uint32_t i = 0; i < n; i++) thr_nodes[i].nchild = i + 1 < thr_nodes[i].link ? i + 1 : thr_nodes[i].link;
+        return;
+    }
+    std::vector<uint32_t> order, stack, kids;
+    order.reserve(n);
+    stack.push_back(0);
+    while (!stack.empty()) {
+        const uint32_t i = stack.back();
+        stack.pop_back();
+        kids.clear();
+        for (uint32_t c = i + 1; c < thr_nodes[i].link; c = thr_nodes[c].link) kids.push_back(c);
+        for (uint32_t c : kids) order.push_back(c);
+        for (size_t k = kids.size(); k-- > 0;) stack.push_back(kids[k]);
+    }
+    order.push_back(0);
+    std::vector<uint32_t> pos(n);
+    for (uint32_t j = 0; j < n; j++) pos[order[j]] = j;
+    std::vector<DevNode> moved(n);
+    api_parallel_ranges(n, (size_t)1 << 15, [&](size_t b, size_t e) {
+        for (size_t j = b; j < e; j++) {
+            const uint32_t i = order[j];
+            DevNode t = thr_nodes[i];
+            const uint32_t skip = t.link >= n ? n : pos[t.link];
+            t.nchild = i + 1 < t.link ? pos[i + 1] : skip;
+            t.link = skip;
+            moved[j] = t;
+        }
+    });
+    thr_nodes.swap(moved);
+    troot_out = n - 1;
 }
 
 int check_scene_call(rtg_scene *scene) {
@@ -619,14 +669,14 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) try {
     *out = nullptr;
     if ((bvh->n_nodes && !bvh->nodes) || (bvh->n_leaves && !bvh->leaves))
         return fail(ctx, RTG_E_INVALID, "rtg_mesh_create: null array with non-zero count");
-    if (bvh->n_nodes >= 0x7FFFFFFFull || bvh->n_leaves >= 0x7FFFFFFFull)
-        return fail(ctx, RTG_E_LIMIT, "rtg_mesh_create: more than 2^31-1 nodes or leaves");
+    if (bvh->n_nodes >= 0x7FFFFFFFull || bvh->n_leaves > 0x40000000ull)
+        return fail(ctx, RTG_E_LIMIT, "rtg_mesh_create: more than 2^31-1 nodes or 2^30 leaves");
     int rc = bind_device(ctx);
     if (rc != RTG_OK) return rc;
 
     std::vector<DevNode> ref_nodes, thr_nodes;
-    uint32_t depth = 0;
-    rc = layout_tree(ctx, bvh, ref_nodes, thr_nodes, depth);
+    uint32_t depth = 0, troot = 0;
+    rc = layout_tree(ctx, bvh, ref_nodes, thr_nodes, depth, troot);
     if (rc != RTG_OK) return rc;
     // Bvh::new (src/tree/bvh.rs:80-106) only ever emits nodes below the root; a tree with stray entries would make
     // the reference-order array (indexed by the caller's ids) and the reachable count disagree
@@ -674,7 +724,7 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) try {
                 }
             }
             hot[i].skip = n.link;
-            hot[i].leaf_ref = n.leaf_count == 0 ? 0xFFFFFFFFu : (n.leaf_count == 1 ? n.leaf_begin : 0x80000000u);
+            hot[i].next = hot_next_word(n.link, n.nchild, n.leaf_begin, n.leaf_count);
         }
         if (nf) not_fast.store(1);
         if (n32) not_f32.store(1);
@@ -730,6 +780,7 @@ int rtg_mesh_create(rtg_ctx *ctx, const rtg_bvh *bvh, rtg_mesh **out) try {
     m->dev.normals = (const double *)m->d_normals;
     m->dev.n_nodes = (uint32_t)n;
     m->dev.root = bvh->root;
+    m->dev.troot = troot;
     m->dev.depth = depth;
     m->dev.fast_div_ok = fast_ok;
     m->dev.f32_ok = f32_ok && std::isfinite(cmax) ? 1u : 0u;
@@ -885,6 +936,7 @@ int rtg_mesh_build(rtg_ctx *ctx, const rtg_tri *triangles, uint64_t n_triangles,
     m->dev.normals = (const double *)m->d_normals;
     m->dev.n_nodes = built.n_nodes;
     m->dev.root = built.root;
+    m->dev.troot = built.troot;
     m->dev.depth = built.depth;
     m->dev.fast_div_ok = built.fast_div_ok;
     m->dev.f32_ok = built.f32_ok && std::isfinite(built.coord_max) ? 1u : 0u;

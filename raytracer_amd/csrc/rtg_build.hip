@@ -18,10 +18,12 @@
 //   * the binary search for the split coordinate follows the probe order of the standard library the reference
 //     used (first probed equal element wins), then the 1 % / 99 % clamp (bvh_subdivide.rs:29-38).
 //
-// Build nodes live in pre-order slots (a subtree over k triangles owns 2k-1 consecutive slots), which is also the
-// threaded layout the traversal kernels read; the position of a node's entry in the reference's flattened order
-// (children after all descendants, root last) follows from the same counts.  The last two kernels write the mesh
-// slab, the reference-order node array and the leaf -> source-triangle map.
+// Build nodes live in pre-order slots (a subtree over k triangles owns 2k-1 consecutive slots); the position of a
+// node's entry in the reference's flattened order (children after all descendants, root last) and its position in
+// the threaded arrays the traversal kernels read (siblings side by side, pairs in pre-order of their parents, root
+// last) follow from the same counts: the inner node at slot s whose triangles start at b is the (s - b)-th inner
+// node in pre-order, so its children sit at 2 (s - b) and 2 (s - b) + 1.  The last two kernels write the mesh slab,
+// the reference-order node array and the leaf -> source-triangle map.
 #include <hip/hip_runtime.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -42,6 +44,7 @@ struct BuildNode {
     uint32_t ref;            // index of this node's entry in the flattened array
     uint32_t split;          // triangles in the left child (0 while unsplit / for a leaf)
     uint32_t axis;           // bits 0..1 sort axis, bit 31 = last of its siblings
+    uint32_t pos;            // position in the threaded arrays
 };
 
 constexpr uint64_t kSign = 0x8000000000000000ull;
@@ -105,7 +108,7 @@ __global__ void k_scatter_rank(const uint32_t *__restrict__ perm, const uint32_t
 
 __global__ void k_init(BuildNode *nodes, uint64_t *bounds, uint32_t n) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        nodes[0] = BuildNode{0u, n, 0u, 2u * n - 2u, 0u, 0x80000000u};
+        nodes[0] = BuildNode{0u, n, 0u, 2u * n - 2u, 0u, 0x80000000u, 2u * n - 2u};
         for (int k = 0; k < 3; k++) {
             bounds[k] = ord_of(kInf);
             bounds[3 + k] = ord_of(-kInf);
@@ -293,8 +296,8 @@ __global__ void k_split(BuildNode *__restrict__ nodes, uint64_t *__restrict__ bo
     if (split > max_split) split = max_split;
     nodes[x].split = split;
     const uint32_t l = x + 1, r = x + 2 * split;
-    nodes[l] = BuildNode{b, split, nd.base, nd.base + 2 * k - 4, 0u, 0u};
-    nodes[r] = BuildNode{b + split, k - split, nd.base + 2 * split - 2, nd.base + 2 * k - 3, 0u, 0x80000000u};
+    nodes[l] = BuildNode{b, split, nd.base, nd.base + 2 * k - 4, 0u, 0u, 2 * (x - b)};
+    nodes[r] = BuildNode{b + split, k - split, nd.base + 2 * split - 2, nd.base + 2 * k - 3, 0u, 0x80000000u, 2 * (x - b) + 1};
     for (int c = 0; c < 3; c++) {
         bounds[(size_t)l * 6 + c] = ord_of(kInf);
         bounds[(size_t)l * 6 + 3 + c] = ord_of(-kInf);
@@ -305,7 +308,8 @@ __global__ void k_split(BuildNode *__restrict__ nodes, uint64_t *__restrict__ bo
     if (k - split >= 2) next_active[atomicAdd(next_count, 1u)] = r;
 }
 
-// Node outputs: the threaded node and its single-precision companion at the pre-order slot, the reference-order
+// Node outputs: the threaded node and its single-precision companion at the node's threaded position (skip link =
+// position of the node in the slot after the subtree, pass link = position of the first child), the reference-order
 // node at the flattened index, and the coordinate-range summary the traversal kernels' fast paths depend on.
 // summary[0] bit 0: some coordinate outside the reciprocal window, bit 1: outside the single-precision window;
 // summary64: bits of the largest |coordinate|.
@@ -323,11 +327,12 @@ __global__ void k_emit_nodes(const BuildNode *__restrict__ nodes, const uint64_t
             t.hi[k] = ord_back(bounds[(size_t)s * 6 + 3 + k]);
         }
         const uint32_t k = nd.count;
-        t.link = s + 2 * k - 1;
-        t.nchild = 0;
+        const uint32_t after = s + 2 * k - 1;
+        t.link = after < n_nodes ? nodes[after].pos : n_nodes;
+        t.nchild = k == 1 ? t.link : 2 * (s - nd.begin);
         t.leaf_begin = nd.begin;
         t.leaf_count = k == 1 ? 1u : 0u;
-        thr[s] = t;
+        thr[nd.pos] = t;
         HotNode h;
         for (int c = 0; c < 3; c++) {
             h.planes[2 * c] = (float)t.lo[c];
@@ -341,8 +346,8 @@ __global__ void k_emit_nodes(const BuildNode *__restrict__ nodes, const uint64_t
             }
         }
         h.skip = t.link;
-        h.leaf_ref = k == 1 ? nd.begin : 0xFFFFFFFFu;
-        hot[s] = h;
+        h.next = hot_next_word(t.link, t.nchild, t.leaf_begin, t.leaf_count);
+        hot[nd.pos] = h;
         DevNode r = t;
         r.link = k == 1 ? nd.base : nd.base + 2 * k - 4;
         r.nchild = (k == 1 ? 0u : 2u) | (nd.axis & 0x80000000u);
@@ -567,6 +572,7 @@ hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uin
     buf.release(normals_out);
     out->n_nodes = n_nodes;
     out->root = n_nodes - 1;
+    out->troot = n_nodes - 1;
     out->depth = depth;
     out->fast_div_ok = (h_small[2] & 1u) ? 0u : 1u;
     out->f32_ok = (h_small[2] & 2u) ? 0u : 1u;

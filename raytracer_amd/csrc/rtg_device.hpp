@@ -25,7 +25,8 @@ struct alignas(16) DevNode {
     double lo[3];
     double hi[3];
     uint32_t link;       // stack layout: first child index; threaded layout: skip (miss) link
-    uint32_t nchild;     // stack layout: bit31 = last sibling, bits 0..30 child count; threaded: unused
+    uint32_t nchild;     // stack layout: bit31 = last sibling, bits 0..30 child count; threaded layout: pass link
+                         // (position of the first child, or the skip link again when the node has no children)
     uint32_t leaf_begin;
     uint32_t leaf_count;
 };
@@ -38,24 +39,42 @@ struct alignas(16) DevTri {
 };
 static_assert(sizeof(DevTri) == 80, "triangle must be 5 x 16 B");
 
+// Threaded nodes name both successors by position, so the array may be in any
+// order: `skip` is where a walk goes on when the box test fails (the node after
+// the subtree in the reference's visit order, or n_nodes at the end), the pass
+// link where it goes on when it passes.  The host and device builders place the
+// children of a node side by side and the pairs in depth-first order of their
+// parents, root last (DevMesh::troot): a visit of a passed node's second child
+// then finds it in the 64-byte half line the first child came with.  Trees in
+// which a node has leaves and children at once keep the pre-order array.
+//
 // 32-byte companion of a threaded node for the single-precision pre-test: the
 // box rounded to f32 with the two planes of an axis side by side (lo.x, hi.x,
 // lo.y, hi.y, lo.z, hi.z: one packed f32 operation handles an axis), the skip
-// link, and the leaf reference (0xFFFFFFFF = no leaves, bit 31 clear = the
-// node's only leaf, bit 31 set = several leaves, read the range from the full
-// node).
+// link, and one word that is either the pass link of a node without leaves
+// (bit 31 clear), the node's only leaf (bit 31 set, bit 30 clear: a leaf node
+// goes on to its skip link), or the mark of any other node (bits 31 and 30 set:
+// several leaves, or leaves and children -- leaf range and pass link are read
+// from the full node).
 struct alignas(16) HotNode {
     float planes[6];
     uint32_t skip;
-    uint32_t leaf_ref;
+    uint32_t next;
 };
 static_assert(sizeof(HotNode) == 32, "hot node must be 2 x 16 B");
+constexpr uint32_t kHotLeaf = 0x80000000u, kHotRange = 0xC0000000u, kHotIndexMask = 0x3FFFFFFFu;
+__host__ __device__ inline uint32_t hot_next_word(uint32_t skip, uint32_t pass, uint32_t leaf_begin, uint32_t leaf_count) {
+    if (leaf_count == 0) return pass;
+    if (leaf_count == 1 && pass == skip && leaf_begin < 0x40000000u) return kHotLeaf | leaf_begin;
+    return kHotRange;
+}
 
 // Everything the persistent kernel reads of a mesh sits in one allocation so a
 // lane keeps one pointer per mesh:
 //   [MeshSlabHeader 64 B][HotNode x n_nodes][threaded DevNode x n_nodes][DevTri x n_leaves]
 // hot node i at +64 + 32 i, threaded node i at +64 + 32 n + 64 i, triangle l at
-// +64 + 96 n + 80 l (all 16-byte aligned).
+// +64 + 96 n + 80 l (all 16-byte aligned); hot node and threaded node of one
+// tree node share their position i.
 struct alignas(16) MeshSlabHeader {
     const rtg_trispline *patches;     // non-null: leaves are facets of trispline patches
     const rtg_patch_leaf *leaf_info;
@@ -66,7 +85,7 @@ static_assert(sizeof(MeshSlabHeader) == 64, "slab header must be 64 B");
 
 struct DevMesh {
     const DevNode *nodes;        // reference order (children after descendants, root last)
-    const DevNode *tnodes;       // pre-order, threaded with skip links
+    const DevNode *tnodes;       // threaded with pass and skip links, walk starts at troot
     const DevTri *tris;
     const double *normals;       // 9 per leaf or nullptr
     uint32_t n_nodes;
@@ -79,7 +98,7 @@ struct DevMesh {
     const rtg_trispline *patches;     // non-null: leaves are facets of trispline patches
     const rtg_patch_leaf *leaf_info;  // per leaf: patch index and corner parameters
     uint32_t newton_steps;
-    uint32_t pad;
+    uint32_t troot;                   // position of the root in the threaded arrays
 };
 
 struct DevMaterial {
@@ -574,14 +593,14 @@ __device__ __forceinline__ void traverse_stack(const DevMesh &m, const Ray &r, H
     }
 }
 
-// Threaded traversal of the pre-order node array: a node whose box test passes
-// is followed by the next array element (its first child, or whatever follows
-// a childless node); a node that fails jumps over its subtree through the skip
-// link.  Same visit order as the recursion, no stack.
+// Threaded traversal: a node whose box test passes is followed by its pass link
+// (its first child, or whatever follows a childless node); a node that fails
+// jumps over its subtree through the skip link.  Same visit order as the
+// recursion, no stack.
 template <bool COUNT, bool PATCH>
 __device__ __forceinline__ void traverse_threaded(const DevMesh &m, const Ray &r, Holder &h, Counter &ctr) {
-    uint32_t cur = 0;
     const uint32_t end = m.n_nodes;
+    uint32_t cur = end ? m.troot : 0u;
     while (cur < end) {
         V3 lo, hi;
         uint4 tail;
@@ -589,7 +608,7 @@ __device__ __forceinline__ void traverse_threaded(const DevMesh &m, const Ray &r
         if (COUNT) ctr.nodes++;
         if (box_hit(lo, hi, r, holder_bound(h))) {
             test_leaves<COUNT, PATCH>(m, tail.z, tail.w, r, h, ctr);
-            cur = cur + 1;
+            cur = tail.y;
         } else {
             cur = tail.x;
         }

@@ -88,7 +88,7 @@ struct BuiltMesh {
     void *d_nodes = nullptr;         // reference-order DevNode x n_nodes
     void *d_leaf_source = nullptr;   // u32 x n: the caller's triangle index of every leaf
     void *d_normals = nullptr;       // 9 doubles per leaf in leaf order, or nullptr
-    uint32_t n_nodes = 0, root = 0, depth = 0, fast_div_ok = 0, f32_ok = 0;
+    uint32_t n_nodes = 0, root = 0, troot = 0, depth = 0, fast_div_ok = 0, f32_ok = 0;   // troot: root's threaded position
     double coord_max = 0.0;
     double bounds[6] = {0, 0, 0, 0, 0, 0};
 };

@@ -563,6 +563,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
     const uint32_t first_id = (uint32_t)s.mesh_objects[0].index;
     const GBytePtr first_slab = (GBytePtr)s.mesh_objects[0].mesh.slab + sizeof(MeshSlabHeader);
     const uint32_t first_end = s.mesh_objects[0].mesh.n_nodes;
+    const uint32_t first_root = s.mesh_objects[0].mesh.troot;
     const bool first_fast_ok = s.mesh_objects[0].mesh.fast_div_ok != 0;
     const float first_coord_max = s.mesh_objects[0].mesh.coord_max;
     // The ray in the current object's space is only read by the triangle and patch steps and by the exact box test
@@ -597,7 +598,8 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
     h.t = kInf;
     h.leaf = RTG_NONE;
     uint32_t obj_i = 0, cur = 0, end_v = 0;
-    uint32_t leaf_cur = 0;        // next leaf to test; bit 31: the node (cur - 1) has several leaves, its range ends the TRI phase
+    uint32_t leaf_cur = 0;        // next leaf to test (low 30 bits), with the kind bits of HotNode::next; bit 30: the leaf is one
+                                  // of a range whose owner `cur` still names (the range's end moves the walk on)
     // With one mesh in the scene (no KEEP) the tree is the same for every lane and every ray: its base and size stay
     // wave-uniform (scalar registers); only scenes with several meshes carry them per lane.
 #define SLAB (KEEP ? slab_v : first_slab)
@@ -625,10 +627,11 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
     // a leaf has been dealt with: next leaf of the node's range (rare), else back to the nodes
     auto leaf_done = [&]() {
         bool more = false;
-        if (leaf_cur & 0x80000000u) {    // rare: the owning node (cur - 1) lists several leaves
+        if (leaf_cur & 0x40000000u) {    // rare: the owning node (cur) lists several leaves, or has children as well
             typedef const vu4 __attribute__((address_space(1))) *U4;
-            vu4 tail = ((U4)((GNodePtr)(SLAB + (uint64_t)END * sizeof(HotNode)) + (cur - 1)))[3];
-            more = (leaf_cur & 0x7FFFFFFFu) + 1 < tail.z + tail.w;
+            vu4 tail = ((U4)((GNodePtr)(SLAB + (uint64_t)END * sizeof(HotNode)) + cur))[3];
+            more = (leaf_cur & kHotIndexMask) + 1 < tail.z + tail.w;
+            if (!more) cur = tail.y;     // the owner's pass link
         }
         leaf_cur++;
         phase = more ? PH_TRI : (cur >= END ? PH_DONE : PH_NODE);
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                                 slab_v = first_slab;
                                 end_v = first_end;
                             }
-                            cur = 0;
+                            cur = first_root;
                             h.has = false;
                             h.t = kInf;
                             h.leaf = RTG_NONE;
@@ -820,7 +823,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                 store_in(in);
                 slab_v = (GBytePtr)o.mesh.slab + sizeof(MeshSlabHeader);
                 end_v = o.mesh.n_nodes;
-                cur = 0;
+                cur = o.mesh.troot;
                 h.has = false;
                 h.t = kInf;
                 h.leaf = RTG_NONE;
@@ -881,12 +884,12 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
             const bool slow_any = PRE || (m_node & m_notfast) != 0;
             const bool pre_all = PRE && (m_node & m_notpre) == 0;
             // The step has no divergent branch on its common path: every lane executes it (a vector instruction costs
-            // the same with 46 or 64 lanes enabled), lanes outside m_node read the root's record -- one more cache
+            // the same with 46 or 64 lanes enabled), lanes outside m_node read the array's first record -- one more cache
             // line per load -- and keep their state through the selects.  That keeps every mask wave-uniform.
             const bool act = lanes_of(m_node);
             bool go_exact = false;
             uint64_t m_go;
-            uint32_t skip, leaf_ref;
+            uint32_t skip, next;       // HotNode::skip, HotNode::next
             if (pre_all) {
                 // single-precision pre-test on the 32-byte companion node
                 typedef const vu4 __attribute__((address_space(1))) *U4;
@@ -907,7 +910,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                 vf2 cy = {__uint_as_float(h0.z), __uint_as_float(h0.w)};
                 vf2 cz = {__uint_as_float(h1.x), __uint_as_float(h1.y)};
                 skip = h1.z;
-                leaf_ref = h1.w;
+                next = h1.w;
                 vf2 qx = __builtin_elementwise_fma(cx, (vf2){r32x, r32x}, (vf2){np32x, np32x});
                 vf2 qy = __builtin_elementwise_fma(cy, (vf2){r32y, r32y}, (vf2){np32y, np32y});
                 vf2 qz = __builtin_elementwise_fma(cz, (vf2){r32z, r32z}, (vf2){np32z, np32z});
@@ -937,7 +940,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                 }
             } else {
                 skip = 0;
-                leaf_ref = 0xFFFFFFFFu;
+                next = 0;
                 if (act) {
                     V3 lo, hi;
                     uint4 tail;
@@ -945,24 +948,28 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                     const Ray in = load_in();
                     go_exact = slow_any ? box_hit_div(lo, hi, in, h.t) : box_hit_fast(lo, hi, in, rcp, h.t);
                     skip = tail.x;
-                    leaf_ref = tail.w == 0 ? 0xFFFFFFFFu : (tail.w == 1 ? tail.z : 0x80000000u);
+                    next = hot_next_word(tail.x, tail.y, tail.z, tail.w);
                 }
                 m_go = wave_ballot(go_exact);
             }
             if (COUNT) ctr.nodes += act ? 1u : 0u;
-            // branch-free successor: a passed box goes on to the next array element, a failed one to the skip link
-            const uint64_t m_to_leaf = m_go & wave_ballot(leaf_ref != 0xFFFFFFFFu);
+            // branch-free successor: a passed box goes on to the node's pass link (a leaf node's is its skip link), a
+            // failed one to the skip link
+            const uint64_t m_leafy = wave_ballot((int32_t)next < 0);
+            const uint64_t m_to_leaf = m_go & m_leafy;
             const bool to_leaf = lanes_of(m_to_leaf);
             const uint32_t node_index = cur;
-            cur = lanes_of(m_go) ? cur + 1 : (act ? skip : cur);
-            leaf_cur = to_leaf ? leaf_ref : leaf_cur;
-            // rare: a node with several leaves (bit 31 of the reference set, and not the "no leaf" pattern)
-            const uint64_t m_range = m_to_leaf & wave_ballot((int32_t)leaf_ref < -1);
+            const uint32_t pass = lanes_of(m_leafy) ? skip : next;
+            cur = lanes_of(m_go) ? pass : (act ? skip : cur);
+            leaf_cur = to_leaf ? next : leaf_cur;
+            // rare: a node with several leaves, or with leaves and children
+            const uint64_t m_range = m_to_leaf & wave_ballot(next >= kHotRange);
             if (m_range != 0) {
                 if (lanes_of(m_range)) {                                     // the range lives in the full node
                     typedef const vu4 __attribute__((address_space(1))) *U4;
                     vu4 t = ((U4)full_node(node_index))[3];
-                    leaf_cur = t.z | 0x80000000u;
+                    leaf_cur = t.z | kHotRange;
+                    cur = node_index;            // the walk stays at the owner until its last leaf is done
                 }
             }
             const uint64_t m_end = wave_ballot(cur >= END) & m_node & ~m_to_leaf;   // traversal finished (resolved below)
@@ -985,7 +992,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
             }
             if (phase == PH_TRI) {
                 V3 v0, v1, v2;
-                const uint32_t leaf = leaf_cur & 0x7FFFFFFFu;
+                const uint32_t leaf = leaf_cur & kHotIndexMask;
                 load_tri_g((GTriPtr)(SLAB + (uint64_t)END * (sizeof(HotNode) + sizeof(DevNode))) + leaf, v0, v1, v2);
                 double t;
                 bool some;
@@ -1025,7 +1032,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
             if (m_solve != 0 && ((uint32_t)__popcll(m_solve) >= solve_thr || wave_ballot(phase == PH_NODE) == 0)) {
                 if (phase == PH_SOLVE) {
                     V3 v0, v1, v2;
-                    const uint32_t leaf = leaf_cur & 0x7FFFFFFFu;
+                    const uint32_t leaf = leaf_cur & kHotIndexMask;
                     load_tri_g((GTriPtr)(SLAB + (uint64_t)END * (sizeof(HotNode) + sizeof(DevNode))) + leaf, v0, v1, v2);
                     const MeshSlabHeader *hdr = (const MeshSlabHeader *)(const uint8_t *)(SLAB - sizeof(MeshSlabHeader));
                     PatchHit ph;
