@@ -456,9 +456,16 @@ int rtg_comm_unique_id(uint8_t id[RTG_COMM_ID_BYTES]);
 /* Collective over the n_ranks callers; `id` may be NULL when n_ranks is 1.  The communicator belongs to `ctx`'s GPU
  * and must be destroyed before the context. */
 int rtg_comm_create(rtg_ctx *ctx, const uint8_t id[RTG_COMM_ID_BYTES], int n_ranks, int rank, rtg_comm **out);
-/* Wraps an ncclComm_t the host already has (not destroyed by rtg_comm_destroy). */
+/* Wraps an ncclComm_t the host already has (not destroyed by rtg_comm_destroy).  The RCCL that made it must be the
+ * copy this process already carried when the library first bound RCCL (RTG_E_UNSUPPORTED otherwise), and it must
+ * report n_ranks ranks. */
 int rtg_comm_adopt(rtg_ctx *ctx, void *nccl_comm, int n_ranks, int rank, rtg_comm **out);
 void rtg_comm_destroy(rtg_comm *comm);
+/* What a communicator is: its rank count and this caller's rank as given at creation, and the rank count RCCL's own
+ * communicator reports (ncclCommCount; 0 when a single rank gathers by device copies and no RCCL communicator exists).
+ * No reference counterpart: it lets a multi-GPU driver (the reference's fan-out script, scripts/request_all.sh:2)
+ * record that the transport really spans the ranks it believes it does.  Any output may be NULL. */
+int rtg_comm_info(const rtg_comm *comm, int *n_ranks, int *rank, int *rccl_ranks);
 
 /* One piece of a gathered frame: `bytes` bytes that rank `rank` holds at `send_offset` of its send buffer and that
  * land at `recv_offset` of the root's receive buffer (a full-width strip of rows lands where it sits in the frame,

@@ -6,9 +6,10 @@
 // and copies its own pieces device-to-device -- enqueued on a stream, so it overlaps the next frame's traversal.
 // Nothing is summed, so there is no ring and no reduction.
 //
-// RCCL is bound at run time (dlopen of librccl.so.1): a process that already carries an RCCL -- e.g. through
-// torch.distributed -- shares that one copy, and the library loads on hosts without RCCL, where a one-rank
-// communicator (plain device copies) still works.
+// RCCL is bound at run time (dlopen of librccl.so.1, first with RTLD_NOLOAD): a process that already carries an
+// RCCL -- e.g. through torch.distributed -- shares that one copy, and the library loads on hosts without RCCL, where
+// a one-rank communicator (plain device copies) still works.  A communicator can only be adopted from the copy the
+// process already carries: handing a foreign ncclComm_t to a second copy of the library would be undefined.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -23,6 +24,7 @@ using rtg::api_fail;
 
 struct rtg_comm {
     rtg_ctx *ctx = nullptr;
+    int device = 0;              // the context's GPU, kept so that destruction does not read the context
     int n_ranks = 1, rank = 0;
     ncclComm_t nccl = nullptr;
     bool owned = false;          // created here (destroyed here) or adopted from the caller
@@ -41,6 +43,8 @@ struct Rccl {
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    bool resident = false;       // the copy was already part of the process when this library first asked for it
     std::string error;
 };
 Rccl g_rccl;
@@ -49,9 +53,16 @@ std::once_flag g_rccl_once;
 const Rccl &rccl() {
     std::call_once(g_rccl_once, [] {
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {                    // the copy the process already carries, if any
+            g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+            if (g_rccl.handle) {
+                g_rccl.resident = true;
+                break;
+            }
+        }
         for (const char *n : names) {
-            g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (g_rccl.handle) break;
+            g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!g_rccl.handle) {
             const char *why = dlerror();
@@ -75,6 +86,7 @@ const Rccl &rccl() {
         g_rccl.Send = (decltype(g_rccl.Send))bind("ncclSend");
         g_rccl.Recv = (decltype(g_rccl.Recv))bind("ncclRecv");
         g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))bind("ncclGetErrorString");
+        g_rccl.CommCount = (decltype(g_rccl.CommCount))bind("ncclCommCount");
         if (!ok) {
             dlclose(g_rccl.handle);
             g_rccl.handle = nullptr;
@@ -113,6 +125,7 @@ int rtg_comm_create(rtg_ctx *ctx, const uint8_t id[RTG_COMM_ID_BYTES], int n_ran
     rtg_comm *c = new (std::nothrow) rtg_comm();
     if (!c) return api_fail(ctx, RTG_E_NOMEM, "out of host memory");
     c->ctx = ctx;
+    c->device = ctx->device;
     c->n_ranks = n_ranks;
     c->rank = rank;
     c->loopback = n_ranks == 1 && ctx->comm_loopback;
@@ -150,10 +163,19 @@ int rtg_comm_adopt(rtg_ctx *ctx, void *nccl_comm, int n_ranks, int rank, rtg_com
     if (n_ranks > 1) {
         if (!nccl_comm) return api_fail(ctx, RTG_E_INVALID, "rtg_comm_adopt: communicator is null");
         if (!rccl().handle) return api_fail(ctx, RTG_E_UNSUPPORTED, "rtg_comm_adopt: %s", rccl().error.c_str());
+        if (!rccl().resident)
+            return api_fail(ctx, RTG_E_UNSUPPORTED,
+                            "rtg_comm_adopt: no RCCL was loaded in this process before the library's own copy, so the "
+                            "communicator belongs to another copy of RCCL");
+        int count = 0;
+        ncclResult_t e = rccl().CommCount((ncclComm_t)nccl_comm, &count);
+        if (e != ncclSuccess || count != n_ranks)
+            return api_fail(ctx, RTG_E_INVALID, "rtg_comm_adopt: the communicator reports %d ranks, the call %d", count, n_ranks);
     }
     rtg_comm *c = new (std::nothrow) rtg_comm();
     if (!c) return api_fail(ctx, RTG_E_NOMEM, "out of host memory");
     c->ctx = ctx;
+    c->device = ctx->device;
     c->n_ranks = n_ranks;
     c->rank = rank;
     c->nccl = (ncclComm_t)nccl_comm;
@@ -167,10 +189,26 @@ int rtg_comm_adopt(rtg_ctx *ctx, void *nccl_comm, int n_ranks, int rank, rtg_com
 void rtg_comm_destroy(rtg_comm *comm) {
     if (!comm) return;
     if (comm->owned && comm->nccl && rccl().handle) {
-        (void)hipSetDevice(comm->ctx->device);
+        (void)hipSetDevice(comm->device);
         (void)rccl().CommDestroy(comm->nccl);
     }
     delete comm;
+}
+
+int rtg_comm_info(const rtg_comm *comm, int *n_ranks, int *rank, int *rccl_ranks) try {
+    if (!comm) return api_fail(nullptr, RTG_E_INVALID, "null communicator");
+    if (n_ranks) *n_ranks = comm->n_ranks;
+    if (rank) *rank = comm->rank;
+    if (rccl_ranks) {
+        *rccl_ranks = 0;                         // no RCCL communicator behind it: one rank, device copies
+        if (comm->nccl && rccl().handle) {
+            ncclResult_t e = rccl().CommCount(comm->nccl, rccl_ranks);
+            if (e != ncclSuccess) return api_fail(comm->ctx, RTG_E_HIP, "ncclCommCount: %s", rccl().GetErrorString(e));
+        }
+    }
+    return RTG_OK;
+} catch (...) {
+    return rtg::api_caught(nullptr, "rtg_comm_info");
 }
 
 int rtg_gather_tiles(rtg_comm *comm, int root, const void *send, void *recv, const rtg_piece *pieces,

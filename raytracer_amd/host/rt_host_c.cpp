@@ -148,33 +148,72 @@ int rth_render_scene_builder_photons(rtg_ctx *ctx, uint64_t time, uint32_t width
 } catch (...) {
     return RTG_E_INTERNAL;
 }
-// bytes of one Radiance picture: the text header and four bytes per pixel
-static uint64_t hdr_bytes(uint32_t width, uint32_t height) {
-    return std::strlen("#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y  +X \n") + std::to_string(height).size() + std::to_string(width).size() +
-           (uint64_t)width * height * 4;
+// upper bound of one Radiance picture's bytes (sizing calls): the text header and, per row, the scanline marker and
+// four components that run-length coding can at worst double
+static uint64_t hdr_bytes_max(uint32_t width, uint32_t height) {
+    return 96 + (uint64_t)height * (4 + 4 * (2 * (uint64_t)width + 2));
 }
 uint64_t rth_to_hdr(const double *rgb, uint32_t width, uint32_t height, uint8_t *out, uint64_t cap) {
-    if (!out) return hdr_bytes(width, height);          // sizing call: nothing is encoded
+    if (!out) return hdr_bytes_max(width, height);      // sizing call: nothing is encoded
     std::vector<uint8_t> b = rt::to_hdr(rgb, width, height);
     if (out && cap >= b.size()) std::memcpy(out, b.data(), b.size());
     return b.size();
 }
 void rth_fibonacci_sphere(uint64_t count, uint64_t seed, double *dirs3) { rt::fibonacci_sphere(count, seed, dirs3); }
 void rth_fibonacci_zenith_y(uint64_t count, uint64_t seed, double *dirs2) { rt::fibonacci_zenith_y(count, seed, dirs2); }
-uint64_t rth_images_tar(const double *rgb, uint32_t width, uint32_t height, double seconds, uint8_t *out, uint64_t cap) {
+uint64_t rth_images_tar(const double *rgb, uint32_t width, uint32_t height, double seconds, const uint32_t *cost,
+                        uint8_t *out, uint64_t cap) {
     if (!out)                                           // sizing call: three members (header block + padded bytes), two end blocks
-        return 3 * (512 + (hdr_bytes(width, height) + 511) / 512 * 512) + 1024;
+        return 3 * (512 + (hdr_bytes_max(width, height) + 511) / 512 * 512) + 1024;
     std::map<std::string, std::vector<uint8_t>> images;                    // Renderer::images (renderer.rs:379-385)
     const size_t n = (size_t)width * height * 3;
     images["image.hdr"] = rt::to_hdr(rgb, width, height);
     std::vector<double> pq(n);
     rt::pq_encode(rgb, n, pq.data());
     images["image.pq.hdr"] = rt::to_hdr(pq.data(), width, height);
-    std::vector<double> perf(n, seconds / ((double)width * height) * 3000.0);
+    std::vector<double> perf = rt::perf_image(seconds, cost, width, height);
     images["perf.hdr"] = rt::to_hdr(perf.data(), width, height);
     std::vector<uint8_t> b = rt::images_tar(images);
     if (out && cap >= b.size()) std::memcpy(out, b.data(), b.size());
     return b.size();
+}
+
+int rth_render_images(rtg_ctx *ctx, const rtg_object *objects, uint32_t n_objects, const rtg_light *lights,
+                      uint32_t n_lights, const double view_orig[3], const double fov[2], uint32_t width, uint32_t height,
+                      uint32_t max_depth, double *out_rgb, rtg_hit *out_hits, uint32_t *out_cost, double *out_seconds,
+                      uint8_t *out_tar, uint64_t cap, uint64_t *tar_bytes) try {
+    if (!ctx || (n_objects && !objects) || (n_lights && !lights) || !view_orig || !fov) return RTG_E_INVALID;
+    rt::Scene scene;
+    scene.size[0] = width;
+    scene.size[1] = height;
+    scene.view = rt::View::from_fov(rt::Vec3{view_orig[0], view_orig[1], view_orig[2]}, fov[0], fov[1]);
+    for (uint32_t i = 0; i < n_lights; i++)
+        scene.lights.push_back(rt::Light{rt::Sphere{rt::Vec3{lights[i].position[0], lights[i].position[1], lights[i].position[2]}, 1.0},
+                                         rt::Color{lights[i].color[0], lights[i].color[1], lights[i].color[2]}});
+    for (uint32_t i = 0; i < n_objects; i++) {
+        rt::Object o;
+        o.c = objects[i];                                 // meshes stay the caller's (no shared handle taken)
+        scene.scene_object.push_back(o);
+    }
+    rt::Renderer r(ctx, std::move(scene));
+    r.max_depth = max_depth;
+    int rc = r.render();
+    if (rc != RTG_OK) return rc;
+    if (out_rgb) std::memcpy(out_rgb, r.radiosity().data(), r.radiosity().size() * sizeof(double));
+    if (out_hits) std::memcpy(out_hits, r.hits().data(), r.hits().size() * sizeof(rtg_hit));
+    if (out_cost) std::memcpy(out_cost, r.pixel_cost().data(), r.pixel_cost().size() * sizeof(uint32_t));
+    if (out_seconds) *out_seconds = r.seconds_pixels();
+    std::vector<uint8_t> tar = rt::images_tar(r.images());
+    if (tar_bytes) *tar_bytes = tar.size();
+    if (out_tar) {
+        if (cap < tar.size()) return RTG_E_LIMIT;
+        std::memcpy(out_tar, tar.data(), tar.size());
+    }
+    return RTG_OK;
+} catch (const std::bad_alloc &) {
+    return RTG_E_NOMEM;
+} catch (...) {
+    return RTG_E_INTERNAL;
 }
 
 } // extern "C"

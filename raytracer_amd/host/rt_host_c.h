@@ -50,11 +50,25 @@ int rth_render_scene_builder(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32
 int rth_render_scene_builder_photons(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32_t height, uint32_t max_depth,
                                      uint64_t photon_count, uint64_t seed, double *out_rgb, uint64_t *n_photons,
                                      double seconds[3]);
-/* Radiance .hdr bytes of an RGB double image; returns the byte count (call with out == NULL to size). */
-/* The three images of Renderer::images (image.hdr, image.pq.hdr, perf.hdr) of an RGB double frame rendered in
- * `seconds`, framed as the tar archive the reference's server returns (bin/server.rs:19-30); returns the byte count. */
-uint64_t rth_images_tar(const double *rgb, uint32_t width, uint32_t height, double seconds, uint8_t *out, uint64_t cap);
+/* Radiance .hdr bytes of an RGB double image as ImageBuilder::to_hdr writes them (src/render/image.rs:44-71);
+ * returns the byte count; called with out == NULL it returns an upper bound to size the buffer with. */
 uint64_t rth_to_hdr(const double *rgb, uint32_t width, uint32_t height, uint8_t *out, uint64_t cap);
+/* The three images of Renderer::images (image.hdr, image.pq.hdr, perf.hdr; src/render/renderer.rs:379-385) of an RGB
+ * double frame rendered in `seconds`, framed as the tar archive the reference's server returns
+ * (src/bin/server.rs:19-30); `cost` (may be NULL: evenly) is the per-pixel work the frame's time is shared out by in
+ * perf.hdr.  Returns the byte count (out == NULL: an upper bound). */
+uint64_t rth_images_tar(const double *rgb, uint32_t width, uint32_t height, double seconds, const uint32_t *cost,
+                        uint8_t *out, uint64_t cap);
+/* Renderer::new(scene).render() and .images() (src/render/renderer.rs:106-154,379-385) over a caller-made scene on
+ * the GPU, the images framed as the server's tar archive: radiosity (3 doubles per pixel), primary hits, the
+ * per-pixel cost behind perf.hdr (nodes visited + triangles tested by the camera ray), the pixel pass's wall time and
+ * the archive.  `view_orig` and `fov` are the eye and the view's two opening angles (View::from_fov); meshes named by the objects stay the
+ * caller's.  Every output may be NULL; RTG_E_LIMIT when `cap` is too small for the archive (*tar_bytes says how
+ * much it needs). */
+int rth_render_images(rtg_ctx *ctx, const rtg_object *objects, uint32_t n_objects, const rtg_light *lights,
+                      uint32_t n_lights, const double view_orig[3], const double fov[2], uint32_t width, uint32_t height,
+                      uint32_t max_depth, double *out_rgb, rtg_hit *out_hits, uint32_t *out_cost, double *out_seconds,
+                      uint8_t *out_tar, uint64_t cap, uint64_t *tar_bytes);
 
 #ifdef __cplusplus
 }

@@ -226,6 +226,7 @@ int Renderer::render() {
         int rc = rtg_render_frame(gpu_scene_, &v, lights.data(), (uint32_t)lights.size(), w, h, rtg_rect{0, 0, w, h},
                                   max_depth, rgb_.data(), nullptr, hits_.data());
         seconds_ = since(t0);
+        if (rc == RTG_OK) rc = pixel_costs();
         return rc;
     }
     // renderer.rs:116-140: a Fibonacci sphere of directions per light, every path behind a specular bounce a photon,
@@ -253,7 +254,23 @@ int Renderer::render() {
                                   nullptr);
     if (rc == RTG_OK) rc = rtg_render_primary(gpu_scene_, &v, w, h, rtg_rect{0, 0, w, h}, hits_.data(), nullptr, nullptr);
     seconds_ = since(t0);
+    if (rc == RTG_OK) rc = pixel_costs();
     return rc;
+}
+
+// The reference times every pixel on its own (renderer.rs:156,174) and shows the times as `perf.hdr`.  A GPU frame
+// has one time for all its pixels; what it does know per pixel is the work of the camera ray: tree nodes visited and
+// triangles tested (the counting build of the traversal kernel, one more primary pass outside the timed part).
+int Renderer::pixel_costs() {
+    const uint32_t w = scene_.size[0], h = scene_.size[1];
+    cost_.assign((size_t)w * h, 0u);
+    if (!perf_per_pixel) return RTG_OK;
+    std::vector<rtg_ray_counters> ctr((size_t)w * h);
+    rtg_view v = scene_.view.c();
+    int rc = rtg_render_primary(gpu_scene_, &v, w, h, rtg_rect{0, 0, w, h}, hits_.data(), nullptr, ctr.data());
+    if (rc != RTG_OK) return rc;
+    for (size_t i = 0; i < ctr.size(); i++) cost_[i] = ctr[i].nodes_visited + ctr[i].tris_tested;
+    return RTG_OK;
 }
 
 double smpte2048_encode(double x) {
@@ -262,9 +279,6 @@ double smpte2048_encode(double x) {
     return std::pow((C1 + C2 * std::pow(x, M1)) / (1.0 + C3 * std::pow(x, M1)), M2);
 }
 
-// Flat (run-length-free) Radiance picture: legal for every reader; the pixel
-// conversion is the shared-exponent RGBE of the `image` crate's HdrEncoder
-// that the reference calls (render/image.rs:63-64).
 // Rows [y0, y1) of a picture, shared among the host's cores: f(row range) for every range.
 template <class F> static void over_rows(uint32_t height, size_t work_per_row, F f) {
     unsigned threads = std::thread::hardware_concurrency();
@@ -289,36 +303,150 @@ template <class F> static void over_rows(uint32_t height, size_t work_per_row, F
     for (auto &th : pool) th.join();
 }
 
-std::vector<uint8_t> to_hdr(const double *rgb, uint32_t width, uint32_t height) {
-    std::string head = "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y " + std::to_string(height) + " +X " + std::to_string(width) + "\n";
-    std::vector<uint8_t> out(head.size() + (size_t)width * height * 4);
-    std::memcpy(out.data(), head.data(), head.size());
-    uint8_t *pixels = out.data() + head.size();
-    over_rows(height, width, [=](uint32_t y0, uint32_t y1) {
-        for (uint32_t y = y0; y < y1; y++)
-            for (uint32_t x = 0; x < width; x++) {
-                const double *p = rgb + ((size_t)y * width + x) * 3;
-                double c[3] = {p[0], p[1], p[2]};
-                if (c[0] != c[0] || c[1] != c[1] || c[2] != c[2]) {      // image.rs:52-58
-                    double v = ((x + y) % 2 == 0) ? 0.0 : 1.0;
-                    c[0] = c[1] = c[2] = v;
+// The Radiance picture the reference's ImageBuilder::write_to produces through the `image` crate's HdrEncoder
+// (render/image.rs:44-66; image 0.24.1, restated from the crate's published source -- the crate is not part of the
+// reference's tree, so its bytes are unpinned here): header with the encoder's comment line, shared-exponent RGBE
+// pixels, and for widths of 8 to 32768 pixels one "new RLE" scanline per row -- the marker 2, 2, width high, width
+// low, then the row's red, green, blue and exponent bytes each compressed on their own; other widths are written
+// flat, four bytes per pixel.
+static void to_rgbe8(const double *p, uint32_t x, uint32_t y, uint8_t px[4]) {
+    double c[3] = {p[0], p[1], p[2]};
+    if (c[0] != c[0] || c[1] != c[1] || c[2] != c[2]) {      // image.rs:52-58
+        double v = ((x + y) % 2 == 0) ? 0.0 : 1.0;
+        c[0] = c[1] = c[2] = v;
+    }
+    float f[3] = {(float)c[0], (float)c[1], (float)c[2]};
+    float mx = std::fmax(f[0], std::fmax(f[1], f[2]));
+    px[0] = px[1] = px[2] = px[3] = 0;
+    if (mx > 0.0f) {
+        int e = (int)std::floor(std::log2(mx)) + 1;
+        float mul = std::ldexp(1.0f, e);
+        for (int k = 0; k < 3; k++) {
+            float q = std::trunc(f[k] / mul * 256.0f);
+            px[k] = (uint8_t)(q < 0.0f ? 0.0f : (q > 255.0f ? 255.0f : q));
+        }
+        px[3] = (uint8_t)(e + 128);
+    }
+}
+
+// The encoder's run-length code for one component of a scanline: the bytes are cut into runs of equal bytes (at
+// most 127 long; a run counts as one from three bytes on) and the stretches between them (at most 128 long, shorter
+// runs folded in); a run is written as 128 + length and the byte, a stretch as its length and its bytes.
+static void rle_compress(const uint8_t *data, size_t n, std::vector<uint8_t> &rle) {
+    if (n == 0) {
+        rle.push_back(0);
+        return;
+    }
+    struct Piece {
+        int kind;          // 0 none, 1 run, 2 stretch
+        uint8_t value;
+        size_t idx, len;
+    };
+    size_t cur = 0;
+    auto next_piece = [&]() {
+        if (cur == n) return Piece{0, 0, 0, 0};
+        const uint8_t cv = data[cur];
+        size_t crun = 0;
+        while (cur + crun < n && data[cur + crun] == cv && crun < 127) crun++;
+        Piece r = crun > 2 ? Piece{1, cv, cur, crun} : Piece{2, cv, cur, crun};
+        cur += crun;
+        return r;
+    };
+    auto emit = [&](const Piece &q) {
+        if (q.kind == 1) {
+            rle.push_back((uint8_t)(128 + q.len));
+            rle.push_back(q.value);
+        } else {
+            rle.push_back((uint8_t)q.len);
+            rle.insert(rle.end(), data + q.idx, data + q.idx + q.len);
+        }
+    };
+    Piece prev{0, 0, 0, 0};
+    for (;;) {
+        Piece held = prev;
+        prev.kind = 0;
+        if (held.kind == 1) {
+            emit(held);
+        } else if (held.kind == 2) {
+            Piece nx = next_piece();
+            if (nx.kind == 2) {
+                const size_t clen = held.len + nx.len;
+                if (clen == 128) {
+                    emit(Piece{2, 0, held.idx, clen});
+                } else if (clen > 128) {
+                    prev = Piece{2, 0, held.idx + 128, clen - 128};
+                    emit(Piece{2, 0, held.idx, 128});
+                } else {
+                    prev = Piece{2, 0, held.idx, clen};
                 }
-                float f[3] = {(float)c[0], (float)c[1], (float)c[2]};
-                float mx = std::fmax(f[0], std::fmax(f[1], f[2]));
-                uint8_t *px = pixels + ((size_t)y * width + x) * 4;
-                px[0] = px[1] = px[2] = px[3] = 0;
-                if (mx > 0.0f) {
-                    int e = (int)std::floor(std::log2(mx)) + 1;
-                    float mul = std::ldexp(1.0f, e);
-                    for (int k = 0; k < 3; k++) {
-                        float q = std::trunc(f[k] / mul * 256.0f);
-                        px[k] = (uint8_t)(q < 0.0f ? 0.0f : (q > 255.0f ? 255.0f : q));
-                    }
-                    px[3] = (uint8_t)(e + 128);
-                }
+            } else {                 // a run follows (kept for the next turn), or the data ends
+                prev = nx;
+                emit(held);
+                if (nx.kind == 0) return;
             }
+        } else {
+            Piece nx = next_piece();
+            if (nx.kind == 0) return;
+            if (nx.kind == 1)
+                emit(nx);
+            else
+                prev = nx;
+        }
+    }
+}
+
+std::vector<uint8_t> to_hdr(const double *rgb, uint32_t width, uint32_t height) {
+    const std::string head = "#?RADIANCE\n# Rust HDR encoder\nFORMAT=32-bit_rle_rgbe\n\n-Y " + std::to_string(height) + " +X " +
+                             std::to_string(width) + "\n";
+    if (width < 8 || width > 32768) {
+        std::vector<uint8_t> out(head.size() + (size_t)width * height * 4);
+        std::memcpy(out.data(), head.data(), head.size());
+        uint8_t *pixels = out.data() + head.size();
+        for (uint32_t y = 0; y < height; y++)
+            for (uint32_t x = 0; x < width; x++)
+                to_rgbe8(rgb + ((size_t)y * width + x) * 3, x, y, pixels + ((size_t)y * width + x) * 4);
+        return out;
+    }
+    std::vector<std::vector<uint8_t>> rows(height);
+    over_rows(height, (size_t)width * 4, [&rows, rgb, width](uint32_t y0, uint32_t y1) {
+        std::vector<uint8_t> comp[4];
+        for (auto &c : comp) c.resize(width);
+        for (uint32_t y = y0; y < y1; y++) {
+            for (uint32_t x = 0; x < width; x++) {
+                uint8_t px[4];
+                to_rgbe8(rgb + ((size_t)y * width + x) * 3, x, y, px);
+                for (int k = 0; k < 4; k++) comp[k][x] = px[k];
+            }
+            std::vector<uint8_t> &row = rows[y];
+            row.reserve((size_t)width * 4 + 64);
+            row.push_back(2);
+            row.push_back(2);
+            row.push_back((uint8_t)(width / 256));
+            row.push_back((uint8_t)(width % 256));
+            for (int k = 0; k < 4; k++) rle_compress(comp[k].data(), width, row);
+        }
     });
+    size_t total = head.size();
+    for (const auto &r : rows) total += r.size();
+    std::vector<uint8_t> out;
+    out.reserve(total);
+    out.insert(out.end(), head.begin(), head.end());
+    for (const auto &r : rows) out.insert(out.end(), r.begin(), r.end());
     return out;
+}
+
+// The frame's time spread over its pixels in proportion to 1 + cost (cost == nullptr: evenly), x 3000 as the
+// reference scales its per-pixel seconds (renderer.rs:152): the perf image.
+std::vector<double> perf_image(double seconds, const uint32_t *cost, uint32_t width, uint32_t height) {
+    const size_t n = (size_t)width * height;
+    std::vector<double> perf(n * 3);
+    double total = 0.0;
+    for (size_t i = 0; i < n; i++) total += 1.0 + (cost ? (double)cost[i] : 0.0);
+    for (size_t i = 0; i < n; i++) {
+        const double v = seconds * ((1.0 + (cost ? (double)cost[i] : 0.0)) / total) * 3000.0;
+        perf[i * 3] = perf[i * 3 + 1] = perf[i * 3 + 2] = v;
+    }
+    return perf;
 }
 
 // ImageBuilder::smpte2048_encode (render/image.rs:33-43): every channel / 80 through the PQ curve.
@@ -337,9 +465,8 @@ std::map<std::string, std::vector<uint8_t>> Renderer::images() const {      // r
     std::vector<double> pq(rgb_.size());
     pq_encode(rgb_.data(), rgb_.size(), pq.data());                                        // image.rs:39
     r["image.pq.hdr"] = to_hdr(pq.data(), w, h);
-    // The reference's perf image is per-pixel CPU time x 3000; a GPU frame has one
-    // time for all pixels, spread evenly.
-    std::vector<double> perf(rgb_.size(), seconds_ / ((double)w * h) * 3000.0);
+    // renderer.rs:152: per-pixel time x 3000 -- here the frame's time shared out by the camera rays' work
+    std::vector<double> perf = perf_image(seconds_, cost_.empty() ? nullptr : cost_.data(), w, h);
     r["perf.hdr"] = to_hdr(perf.data(), w, h);
     return r;
 }

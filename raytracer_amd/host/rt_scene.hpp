@@ -124,6 +124,9 @@ class Renderer {
     std::map<std::string, std::vector<uint8_t>> images() const;   // image.hdr, image.pq.hdr, perf.hdr
     const std::vector<double> &radiosity() const { return rgb_; }
     const std::vector<rtg_hit> &hits() const { return hits_; }
+    // per pixel: tree nodes visited + triangles tested by the camera ray (what perf.hdr shares the frame's time by)
+    const std::vector<uint32_t> &pixel_cost() const { return cost_; }
+    bool perf_per_pixel = true;                   // false: no counting pass, perf.hdr spreads the time evenly
     const char *error() const;
     uint32_t max_depth = 4;                       // renderer.rs:312
     bool photon_pass = false;
@@ -141,6 +144,8 @@ class Renderer {
     rtg_scene *gpu_scene_ = nullptr;
     std::vector<double> rgb_;
     std::vector<rtg_hit> hits_;
+    std::vector<uint32_t> cost_;
+    int pixel_costs();
     double seconds_ = 0, seconds_dirs_ = 0, seconds_photons_ = 0;
     rtg_photon_map *photon_map_ = nullptr;
     uint64_t n_photons_ = 0;
@@ -149,8 +154,11 @@ class Renderer {
 std::shared_ptr<GpuMesh> upload_mesh(rtg_ctx *ctx, Bvh bvh);
 
 // Radiance RGBE (.hdr) writer for a row-major RGB double image; NaN pixels
-// become the reference's checkerboard (render/image.rs:44-66).
+// become the reference's checkerboard (render/image.rs:44-66); run-length coded scanlines as the `image` crate's
+// HdrEncoder writes them.
 std::vector<uint8_t> to_hdr(const double *rgb, uint32_t width, uint32_t height);
+// RGB image of the per-pixel times x 3000 (renderer.rs:152): `seconds` shared out in proportion to 1 + cost[i].
+std::vector<double> perf_image(double seconds, const uint32_t *cost, uint32_t width, uint32_t height);
 // The tar archive of Renderer::images() as the reference's server frames it (bin/server.rs:19-30).
 std::vector<uint8_t> images_tar(const std::map<std::string, std::vector<uint8_t>> &images);
 double smpte2048_encode(double x);   // geo/color.rs:15-17

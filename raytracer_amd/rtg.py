@@ -160,6 +160,7 @@ _sig(lib.rtg_comm_unique_id, C.c_int, _vp)
 _sig(lib.rtg_comm_create, C.c_int, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp))
 _sig(lib.rtg_comm_adopt, C.c_int, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp))
 _sig(lib.rtg_comm_destroy, None, _vp)
+_sig(lib.rtg_comm_info, C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig(lib.rtg_gather_tiles, C.c_int, _vp, C.c_int, _vp, _vp, C.POINTER(Piece), C.c_uint32, _vp)
 
 _sig(host.rth_bvh_build_subdivide, _vp, _vp, C.c_uint64, _vp, C.c_int)
@@ -183,7 +184,10 @@ _sig(host.rth_render_scene_builder, C.c_int, _vp, C.c_uint64, C.c_uint32, C.c_ui
 _sig(host.rth_render_scene_builder_photons, C.c_int, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _vp,
      C.POINTER(C.c_uint64), _vp)
 _sig(host.rth_to_hdr, C.c_uint64, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64)
-_sig(host.rth_images_tar, C.c_uint64, _vp, C.c_uint32, C.c_uint32, C.c_double, _vp, C.c_uint64)
+_sig(host.rth_images_tar, C.c_uint64, _vp, C.c_uint32, C.c_uint32, C.c_double, _vp, _vp, C.c_uint64)
+_sig(host.rth_render_images, C.c_int, _vp, C.POINTER(Object), C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_double),
+     C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, C.POINTER(C.c_double), _vp, C.c_uint64,
+     C.POINTER(C.c_uint64))
 
 
 def _ptr(a):
@@ -522,6 +526,12 @@ class Comm:
             arr[i].rank, arr[i].send_offset, arr[i].recv_offset, arr[i].bytes = r, so, ro, nb
         self.ctx._check(lib.rtg_gather_tiles(self._h, root, _ptr(send_ptr), _ptr(recv_ptr), arr, len(pieces),
                                              C.c_void_p(stream_handle) if stream_handle else None))
+
+    def info(self):
+        """(ranks, this rank, ranks RCCL's communicator reports -- 0 when one rank gathers by device copies)."""
+        n, r, c = C.c_int(), C.c_int(), C.c_int()
+        self.ctx._check(lib.rtg_comm_info(self._h, C.byref(n), C.byref(r), C.byref(c)))
+        return n.value, r.value, c.value
 
     def close(self):
         if self._h:
@@ -886,17 +896,42 @@ def render_scene_builder_photons(ctx, time, width, height, photon_count, seed=1,
 
 
 def to_hdr(rgb, width, height):
+    """ImageBuilder::to_hdr: the Radiance picture of an RGB frame, scanlines run-length coded."""
     rgb = np.ascontiguousarray(rgb, dtype=np.float64)
-    n = host.rth_to_hdr(_ptr(rgb), width, height, None, 0)
-    out = np.empty(n, dtype=np.uint8)
-    host.rth_to_hdr(_ptr(rgb), width, height, _ptr(out), n)
-    return out.tobytes()
+    cap = host.rth_to_hdr(_ptr(rgb), width, height, None, 0)
+    out = np.empty(cap, dtype=np.uint8)
+    n = host.rth_to_hdr(_ptr(rgb), width, height, _ptr(out), cap)
+    return out[:n].tobytes()
 
 
-def images_tar(rgb, width, height, seconds=0.0):
-    """Renderer::images() framed as the reference server's tar archive."""
+def images_tar(rgb, width, height, seconds=0.0, cost=None):
+    """Renderer::images() framed as the reference server's tar archive; `cost` (uint32 per pixel) is what perf.hdr
+    shares `seconds` out by (None: evenly)."""
     rgb = np.ascontiguousarray(rgb, dtype=np.float64)
-    n = host.rth_images_tar(_ptr(rgb), width, height, seconds, None, 0)
-    out = np.empty(n, dtype=np.uint8)
-    host.rth_images_tar(_ptr(rgb), width, height, seconds, _ptr(out), n)
-    return out.tobytes()
+    if cost is not None:
+        cost = np.ascontiguousarray(cost, dtype=np.uint32)
+        assert cost.size == width * height
+    cap = host.rth_images_tar(_ptr(rgb), width, height, seconds, None, None, 0)
+    out = np.empty(cap, dtype=np.uint8)
+    n = host.rth_images_tar(_ptr(rgb), width, height, seconds, None if cost is None else _ptr(cost), _ptr(out), cap)
+    return out[:n].tobytes()
+
+
+def render_images(ctx, objects, lights, view_orig, fov, width, height, max_depth=4):
+    """Renderer::new(scene).render() and .images() on the GPU through the C++ host mirror, the images framed as the
+    server's tar archive: (rgb, hits, per-pixel cost, seconds of the pixel pass, tar bytes)."""
+    objs = (Object * len(objects))(*objects)
+    lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+    orig = (C.c_double * 3)(*view_orig)
+    fov2 = (C.c_double * 2)(*fov)
+    rgb = np.empty((height * width, 3), dtype=np.float64)
+    hits = np.empty(height * width, dtype=HIT_DTYPE)
+    cost = np.empty(height * width, dtype=np.uint32)
+    seconds = C.c_double()
+    need = C.c_uint64()
+    cap = host.rth_images_tar(_ptr(rgb), width, height, 0.0, None, None, 0)
+    tar = np.empty(cap, dtype=np.uint8)
+    ctx._check(host.rth_render_images(ctx._h, objs, len(objects), _ptr(lights), len(lights), orig, fov2, width, height,
+                                      max_depth, _ptr(rgb), _ptr(hits), _ptr(cost), C.byref(seconds), _ptr(tar), cap,
+                                      C.byref(need)))
+    return rgb, hits, cost, seconds.value, tar[:need.value].tobytes()

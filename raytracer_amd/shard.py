@@ -153,6 +153,16 @@ def gather_pieces(send: torch.Tensor, recv, pieces, dst: int = 0, group=None):
             req.wait()
 
 
+def _gather_finished(device, gather):
+    """After a caller-supplied gather: a native gather (rtg.Comm.gather) enqueues its copies and RCCL transfers on a
+    stream torch knows nothing about, so nothing torch does afterwards -- reading the assembled result on the root,
+    rendering the next piece into the send buffer on any rank -- is ordered behind it.  The GPU is drained here, once
+    per gather; a caller that wants the gather to overlap other work drives rtg_gather_tiles itself with events, as
+    bench.py does.  The default gather runs through torch.distributed on the current stream and needs none of this."""
+    if gather is not None and torch.device(device).type != "cpu":
+        torch.cuda.synchronize(torch.device(device))
+
+
 def render_frame_tiles(render_rect, width: int, height: int, channels: int, dtype, device, interleave: int = 4,
                        dst: int = 0, group=None, gather=None):
     """Tile mode: this rank renders its strips with `render_rect(rect, out_flat_tensor)` back to back into its send
@@ -177,6 +187,7 @@ def render_frame_tiles(render_rect, width: int, height: int, channels: int, dtyp
         gather_pieces(send_b, recv_b, pieces, dst, group)
     else:
         gather(send_b, recv_b, pieces)
+    _gather_finished(device, gather)
     return frame
 
 
@@ -202,9 +213,8 @@ def render_sequence_frames(render_frame, n_frames: int, frame_elems: int, dtype,
             gather_pieces(send_b, recv_b, pieces, dst, group)
         else:
             gather(send_b, recv_b, pieces)
+        _gather_finished(device, gather)      # every rank: `local` is rendered into again in the next round
         if rank == dst:
-            if gather is not None and device != "cpu":
-                torch.cuda.synchronize()
             for r in range(world):
                 if live[r]:
                     out[base + r] = slots[r].clone()
@@ -230,4 +240,5 @@ def trace_rays_sharded(trace, n_rays: int, record_elems: int, dtype, device, dst
         gather_pieces(send_b, recv_b, pieces, dst, group)
     else:
         gather(send_b, recv_b, pieces)
+    _gather_finished(device, gather)
     return out

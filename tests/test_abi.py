@@ -72,6 +72,7 @@ def test_null_arguments_are_errors_not_crashes():
     assert rtg.lib.rtg_render_primary_static(None, None, 1, 1, rtg.Rect(0, 0, 1, 1), None) == -1
     assert rtg.lib.rtg_gather_tiles(None, 0, None, None, None, 0, None) == -1
     assert rtg.lib.rtg_comm_create(None, None, 1, 0, None) == -1
+    assert rtg.lib.rtg_comm_info(None, None, None, None) == -1
     rtg.lib.rtg_ctx_destroy(None)
     rtg.lib.rtg_mesh_destroy(None)
     rtg.lib.rtg_scene_destroy(None)

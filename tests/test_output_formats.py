@@ -8,17 +8,128 @@ import numpy as np
 from raytracer_amd import rtg
 
 
-def _decode_hdr(data):
+def _unrle(buf, pos, width):
+    """One run-length coded component of a scanline (the Radiance "new RLE": a count above 128 repeats the next
+    byte count - 128 times, any other count copies that many bytes)."""
+    out = bytearray()
+    while len(out) < width:
+        c = buf[pos]
+        pos += 1
+        if c > 128:
+            out += bytes([buf[pos]]) * (c - 128)
+            pos += 1
+        else:
+            assert c > 0
+            out += buf[pos:pos + c]
+            pos += c
+    assert len(out) == width
+    return out, pos
+
+
+def decode_hdr_bytes(data):
+    """(height, width, 4) RGBE bytes of a Radiance picture, scanlines run-length coded or flat."""
     head, _, rest = data.partition(b"\n\n")
     assert head.startswith(b"#?RADIANCE") and b"FORMAT=32-bit_rle_rgbe" in head
     dims, _, pixels = rest.partition(b"\n")
-    _, h, _, w = dims.split()
+    my, h, px_, w = dims.split()
+    assert (my, px_) == (b"-Y", b"+X")
     w, h = int(w), int(h)
-    px = np.frombuffer(pixels, dtype=np.uint8)
-    assert px.size == w * h * 4                      # flat (not run-length encoded) scanlines
-    px = px.reshape(h, w, 4).astype(np.float64)
+    if not 8 <= w <= 32768:
+        assert len(pixels) == w * h * 4                  # flat: four bytes per pixel
+        return np.frombuffer(pixels, dtype=np.uint8).reshape(h, w, 4)
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    pos = 0
+    for y in range(h):
+        assert pixels[pos:pos + 4] == bytes([2, 2, w >> 8, w & 255])
+        pos += 4
+        for k in range(4):
+            comp, pos = _unrle(pixels, pos, w)
+            out[y, :, k] = np.frombuffer(bytes(comp), dtype=np.uint8)
+    assert pos == len(pixels)
+    return out
+
+
+def _decode_hdr(data):
+    px = decode_hdr_bytes(data).astype(np.float64)
     scale = np.where(px[:, :, 3:] > 0, np.ldexp(1.0, px[:, :, 3:].astype(int) - 136), 0.0)
     return px[:, :, :3] * scale
+
+
+def _rle_by_the_book(data):
+    """The run-length code of the `image` crate's HdrEncoder, restated from its description: runs of equal bytes
+    (3 to 127 long) become (128 + length, byte); everything between runs is cut into stretches of at most 128 bytes,
+    each written as (length, bytes)."""
+    n = len(data)
+    pieces = []                       # ("run", value, length) / ("raw", start, length), raw pieces not yet merged
+    i = 0
+    while i < n:
+        j = i
+        while j < n and data[j] == data[i] and j - i < 127:
+            j += 1
+        pieces.append(("run", data[i], j - i) if j - i > 2 else ("raw", i, j - i))
+        i = j
+    out = bytearray()
+    k = 0
+    while k < len(pieces):
+        if pieces[k][0] == "run":
+            out += bytes([128 + pieces[k][2], pieces[k][1]])
+            k += 1
+            continue
+        start, length = pieces[k][1], 0
+        while k < len(pieces) and pieces[k][0] == "raw":
+            length += pieces[k][2]
+            k += 1
+        while length > 0:
+            take = min(128, length)
+            out += bytes([take]) + bytes(data[start:start + take])
+            start += take
+            length -= take
+    return bytes(out) if n else b"\x00"
+
+
+def _scanline_bytes(rgbe_row):
+    w = rgbe_row.shape[0]
+    out = bytes([2, 2, w >> 8, w & 255])
+    for k in range(4):
+        out += _rle_by_the_book(rgbe_row[:, k].tobytes())
+    return out
+
+
+def test_scanlines_are_run_length_coded_like_the_reference_encoder():
+    """render/image.rs:63-64 writes through image 0.24.1's HdrEncoder: header with the encoder's comment line, one
+    new-RLE scanline per row for widths 8..32768, flat pixels otherwise.  Known cases by hand, then random rows with
+    long runs, short runs (two equal bytes are not a run), stretches longer than 128 and runs longer than 127."""
+    def comp(values):                              # one row whose red channel quantises to `values` (exponent 128)
+        row = np.zeros((1, len(values), 3))
+        row[0, :, 0] = (np.asarray(values) + 0.5) / 256.0
+        row[0, :, 1] = 0.999                         # pins the exponent: max channel in [0.5, 1)
+        data = rtg.to_hdr(row, len(values), 1)
+        px = data.partition(b"\n\n")[2].partition(b"\n")[2]
+        assert px[:4] == bytes([2, 2, len(values) >> 8, len(values) & 255])
+        want = _rle_by_the_book(bytes(values))
+        assert px[4:4 + len(want)] == want
+        return want
+    assert comp([1, 1, 1, 2, 3, 9, 9, 9, 9]) == bytes([131, 1, 2, 2, 3, 132, 9])
+    assert comp([1, 1, 2, 2, 3, 3, 4, 4]) == bytes([8, 1, 1, 2, 2, 3, 3, 4, 4])
+    assert comp([5] * 300) == bytes([255, 5, 255, 5, 128 + 46, 5])
+    alt = [i % 2 for i in range(200)]
+    assert comp(alt) == bytes([128] + alt[:128] + [72] + alt[128:])
+    assert comp(alt[:127] + [7, 7] + [3] * 9) == bytes([128] + alt[:127] + [7] + [1, 7] + [137, 3])
+    head = rtg.to_hdr(np.zeros((1, 8, 3)), 8, 1).partition(b"\n\n")[0]
+    assert head == b"#?RADIANCE\n# Rust HDR encoder\nFORMAT=32-bit_rle_rgbe"
+    rng = np.random.default_rng(11)
+    for w in (8, 9, 127, 128, 129, 300, 1000):
+        rgb = rng.uniform(0.0, 2.0, size=(6, w, 3))
+        rgb[1] = 0.25                                # a constant row: runs only
+        rgb[2, : w // 2] = 3.0                       # half run, half noise
+        rgb[3, ::3] = 0.0
+        rgb[4] = np.repeat(rng.uniform(0, 1, size=(w + 1) // 2), 2)[:w, None]     # pairs: never a run
+        data = rtg.to_hdr(rgb, w, 6)
+        rgbe = decode_hdr_bytes(data)
+        px = data.partition(b"\n\n")[2].partition(b"\n")[2]
+        assert px == b"".join(_scanline_bytes(rgbe[y]) for y in range(6))
+    flat = rtg.to_hdr(rng.uniform(0, 1, size=(3, 7, 3)), 7, 3)          # narrower than 8: no run-length coding
+    assert len(flat.partition(b"\n\n")[2].partition(b"\n")[2]) == 7 * 3 * 4
 
 
 def test_hdr_round_trip_within_rgbe_precision():
@@ -42,10 +153,17 @@ def test_images_tar_holds_the_three_images():
             assert m.isfile() and m.mode == 0o700 and m.mtime == 0
         assert tar.extractfile(members["image.hdr"]).read() == rtg.to_hdr(rgb, 16, 9)
         perf = _decode_hdr(tar.extractfile(members["perf.hdr"]).read())
-        want = 0.5 / (16 * 9) * 3000.0                # per-pixel time x 3000 (renderer.rs:152)
+        want = 0.5 / (16 * 9) * 3000.0                # per-pixel time x 3000 (renderer.rs:152), no cost given: evenly
         assert np.all(np.abs(perf - want) <= want / 128.0)
         pq = _decode_hdr(tar.extractfile(members["image.pq.hdr"]).read())
         assert np.all((pq >= 0.0) & (pq <= 1.0))
+    # with a per-pixel cost the frame's time is shared out in proportion to 1 + cost
+    cost = rng.integers(0, 200, size=16 * 9).astype(np.uint32)
+    with tarfile.open(fileobj=io.BytesIO(rtg.images_tar(rgb, 16, 9, seconds=0.5, cost=cost))) as tar:
+        perf = _decode_hdr(tar.extractfile("perf.hdr").read())
+    want = 0.5 * (1.0 + cost) / (1.0 + cost).sum() * 3000.0
+    assert np.all(np.abs(perf - want.reshape(9, 16, 1)) <= want.reshape(9, 16, 1) / 128.0)
+    assert abs(perf[:, :, 0].sum() / 3000.0 - 0.5) < 0.5 / 100.0        # the times still add up to the frame's
 
 
 def test_large_images_encode_like_their_rows():
@@ -65,6 +183,10 @@ def test_large_images_encode_like_their_rows():
         piece = rtg.to_hdr(np.ascontiguousarray(rgb[y0:y0 + 2]), w, min(2, h - y0))
         strips += piece.partition(b"\n\n")[2].partition(b"\n")[2]
     assert pixels == strips
+    nan_px = np.isnan(rgb).any(axis=2)
+    board = decode_hdr_bytes(whole)[nan_px]
+    yy, xx = np.nonzero(nan_px)
+    assert np.array_equal(board[:, 3] != 0, (xx + yy) % 2 == 1)         # black / white by (x + y) parity
     blob = rtg.images_tar(rgb, w, h, seconds=1.25)
     with tarfile.open(fileobj=io.BytesIO(blob)) as tar:
         members = {m.name: m for m in tar.getmembers()}
@@ -73,7 +195,8 @@ def test_large_images_encode_like_their_rows():
     small = rtg.images_tar(np.ascontiguousarray(rgb[:2]), w, 2)
     with tarfile.open(fileobj=io.BytesIO(small)) as tar:
         pq_small = tar.extractfile("image.pq.hdr").read()
-    assert pq.partition(b"\n\n")[2].partition(b"\n")[2][: w * 2 * 4] == pq_small.partition(b"\n\n")[2].partition(b"\n")[2]
+    first_two = pq_small.partition(b"\n\n")[2].partition(b"\n")[2]
+    assert pq.partition(b"\n\n")[2].partition(b"\n")[2][: len(first_two)] == first_two
 
 
 def test_fibonacci_sphere_directions():
