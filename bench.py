@@ -30,8 +30,16 @@ kernel behind rtg_render_primary):
 The launch duration comes from HIP events that the launch itself fills with its execution window on the launching
 stream; with two launches in flight a launch spans the time it shares the GPU with its neighbour
 (`concurrent_launches`).  `configs.c4` is the same for configuration 4 (64 M incoherent rays against 10 M triangles,
-the HBM-resident case).  `cpu_baseline` is the oracle (C++ restatement of the reference renderer, kind "port") timed
-on this host's cores on whole frames of the same sequence.
+the HBM-resident case), `configs.c3` for configuration 3 (3840x2160 camera rays against 15 500 trispline patches) and
+`configs.c5` is configuration 5 on this GPU (the 3840x2160 frame sequence shaded to 8-bit colour under the orbiting
+lights).  `cpu_baseline` is the oracle (C++ restatement of the reference renderer, kind "port") timed on this host's
+cores on whole frames of the same sequence.
+
+With N > 1 the line also carries `gather`: the rank count RCCL's communicator reports, bytes gathered per step, the
+gather's own duration and rate per sending rank, and the time the traversal streams spent waiting for a hit buffer
+whose gather had not finished.  A gather that cannot be set up natively ends the run with a non-zero exit (unless
+`--gather torch` asked for the torch path), and so does a first gather that has not completed after
+`--gather-timeout` seconds (what is pending is printed first).
 """
 import argparse
 import json
@@ -84,15 +92,17 @@ def committed(name, workload_key, kernel):
 
 
 def roofline_record(kernel, workload_key, kernel_ms, n_rays, nodes_per_ray, tris_per_ray, ray_in_bytes, use_committed,
-                    tree=None):
+                    tree=None, leaf_bytes=72.0):
     """The `roofline` object.  Two ceilings are priced -- `gather` (the rate at which the CUs' vector memory path
     serves the node fetches, per cache level) and `hbm` (counter traffic against HBM peak) -- and the top-level
     bound / achieved / peak / frac are those of the one that binds (the larger fraction).  `algorithmic` is the byte
     rate the traversal asks for, for information; `compulsory` (given `tree` = (nodes, leaves)) is the least a launch
     could move: the scene as the kernel stores it, once (32-byte hot nodes, 80-byte triangle records), the rays in and
-    the hit records out."""
+    the hit records out.  `little` is the latency ceiling: with one node fetch in flight per resident ray, no more
+    than (rays resident on the chip) / (measured latency of a vector-memory instruction) visits can complete per
+    second, whatever the caches deliver."""
     seconds = kernel_ms * 1e-3
-    bytes_per_ray = nodes_per_ray * 64.0 + tris_per_ray * 72.0 + ray_in_bytes + 16.0
+    bytes_per_ray = nodes_per_ray * 64.0 + tris_per_ray * leaf_bytes + ray_in_bytes + 16.0
     visits_per_s = nodes_per_ray * n_rays / seconds
     ceiling = committed("ceiling.json", workload_key, kernel) if use_committed else None
     traffic = committed("traffic.json", workload_key, kernel) if use_committed else None
@@ -106,13 +116,16 @@ def roofline_record(kernel, workload_key, kernel_ms, n_rays, nodes_per_ray, tris
     if traffic is not None:
         b = float(traffic["hbm_bytes_per_launch"])
         hbm = {"bound": "hbm", "achieved": round(b / seconds / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": round(b / seconds / 1e9 / HBM_PEAK_GBS, 4), "source": traffic["file"]}
+               "frac": round(b / seconds / 1e9 / HBM_PEAK_GBS, 4), "source": traffic["file"],
+               "what": "L2 -> fabric traffic per launch (2 x FETCH_SIZE + WRITE_SIZE; reads served by the Infinity "
+                       "Cache are counted, so this is an upper bound on HBM utilisation: no counter on this GPU "
+                       "splits them -- TCC_EA0_RDREQ_DRAM equals TCC_EA0_RDREQ) against the 8 TB/s HBM peak"}
     binding = hbm if (hbm is not None and (gather["frac"] is None or hbm["frac"] > gather["frac"])) else gather
     rec = {k: binding[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
     rec.update({"traffic": None if traffic is None else round(float(traffic["hbm_bytes_per_launch"]) / 1e9, 4),
                 "traffic_unit": "GB per launch", "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
                 "nodes_per_ray": round(float(nodes_per_ray), 2), "tris_per_ray": round(float(tris_per_ray), 2),
-                "gather": gather, "hbm": hbm,
+                "gather": gather, "hbm": hbm, "little": little_record(kernel, workload_key, visits_per_s, use_committed),
                 "algorithmic": {"bytes_per_ray": round(bytes_per_ray, 1),
                                 "gbs": round(bytes_per_ray * n_rays / seconds / 1e9, 1),
                                 "note": "bytes the traversal asks for; mostly cache hits, not HBM traffic"}})
@@ -123,6 +136,95 @@ def roofline_record(kernel, workload_key, kernel_ms, n_rays, nodes_per_ray, tris
                              round(float(traffic["hbm_bytes_per_launch"]) / least, 2),
                              "note": "scene once (32-byte hot nodes, 80-byte triangles) + rays in + hit records out"}
     return rec
+
+
+def little_record(kernel, workload_key, visits_per_s, use_committed):
+    """Little's-law ceiling of a kernel whose rays each keep one dependent node fetch in flight: resident rays /
+    measured vector-memory latency (profiles/<round>/latency*.json, from the SQ counters of tools/prof_latency.sh)."""
+    lat = committed("latency.json", workload_key, kernel) if use_committed else None
+    if lat is None:
+        return None
+    rays_resident = 1024 * lat["waves_per_simd"] * 64                    # 256 CUs x 4 SIMDs, 64 lanes per wave
+    ceiling = rays_resident / (lat["vmem_latency_cycles"] / (lat["clock_ghz"] * 1e9))
+    return {"bound": "latency (Little's law): resident rays / vector-memory latency", "unit": "G node visits/s",
+            "achieved": round(visits_per_s / 1e9, 2), "peak": round(ceiling / 1e9, 1),
+            "frac": round(visits_per_s / ceiling, 4), "rays_resident": rays_resident,
+            "vmem_latency_cycles": lat["vmem_latency_cycles"], "clock_ghz": lat["clock_ghz"], "source": lat["file"],
+            "note": "a wave waits for the slowest of its lanes and issues ~50 instructions per step as well, so a "
+                    "step takes two to three such latencies; the ceiling prices the latency alone"}
+
+
+def run_config3(rtg, torch, ctx, dev, launches=5):
+    """Configuration 3 on one GPU: 3840x2160 camera rays against 15 500 trispline patches (992 000 facets in the
+    tree, Newton refinement on the patch), hit records only.  Returns the `configs.c3` record."""
+    W, H = 3840, 2160
+    t0 = time.time()
+    patches = rtg.patch_terrain(125, 62, seed=SEED, scale=LOCAL_SCALE)
+    pm = rtg.HostPatchMesh(patches, k=8, newton_steps=5)
+    mesh = ctx.mesh(pm)
+    scene = ctx.scene([rtg.patch_object(mesh, rtg.material((1, 1, 1)), rtg.transform(1.0 / LOCAL_SCALE))])
+    view = rtg.make_view()
+    n = W * H
+    tile = (0, 0, W, H)
+    hits = torch.empty(n * 16, dtype=torch.uint8, device=dev)
+    ctr = torch.empty(n * 2, dtype=torch.int32, device=dev)
+    scene.render_primary_raw(view, W, H, tile, hits.data_ptr(), None, ctr.data_ptr())
+    ctx.synchronize()
+    setup_s = time.time() - t0
+    c = ctr.view(n, 2).to(torch.int64).sum(dim=0).cpu().numpy()
+    del ctr
+    scene.render_primary_raw(view, W, H, tile, hits.data_ptr())
+    ctx.synchronize()
+    ctx.set_option("time_kernels", 2)
+    ctx.kernel_time()
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        scene.render_primary_raw(view, W, H, tile, hits.data_ptr())
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    ms, k = ctx.kernel_time()
+    ctx.set_option("time_kernels", 1)
+    assert k == launches
+    n_hit = int((hits.view(torch.int32).view(n, 4)[:, 1] != -1).sum().item())
+    rec = {"workload": f"config 3: {W}x{H} primary rays vs {len(patches)} trispline patches ({pm.bvh.n_leaves} facets, "
+                       f"{pm.bvh.n_nodes} nodes, depth {pm.bvh.depth}), closest-hit ids",
+           "value": round(n * launches / wall / 1e6, 1), "unit": "Mrays/s", "launches": launches,
+           "ms_per_launch": round(wall / launches * 1e3, 3), "rays_hit": n_hit, "setup_s": round(setup_s, 2),
+           "roofline": roofline_record("k_trace_phased", "config3-3840x2160-patches", ms / launches, n, c[0] / n, c[1] / n,
+                                       0.0, True, (pm.bvh.n_nodes, pm.bvh.n_leaves), leaf_bytes=72.0 + 240.0)}
+    scene.close()
+    mesh.close()
+    return rec
+
+
+def run_config5(rtg, torch, ctx, dev, scene, frames=24):
+    """Configuration 5 on one GPU: a sequence of 3840x2160 frames of the 1 000 000-triangle terrain, shaded to 8-bit
+    colour under the two lights of SceneBuilder{time} (src/lib.rs:90-102), frame f at time f (the loop of
+    src/bin/local.rs:42-50).  With several GPUs the frames go to the ranks in turn and every frame's payload is
+    gathered (tools/config5.py); here the one GPU renders them all.  Returns the `configs.c5` record."""
+    W, H = 3840, 2160
+    out = [torch.empty(W * H * 4, dtype=torch.uint8, device=dev) for _ in range(2)]
+    lights = []
+    for f in range(frames):
+        _, l, view = rtg.scene_builder(f)
+        lights.append(np.ascontiguousarray(l, dtype=rtg.LIGHT_DTYPE))
+
+    def frame(f):
+        scene.render_frame_raw(view, lights[f], len(lights[f]), W, H, (0, 0, W, H), 4, None, out[f & 1].data_ptr(), None)
+
+    frame(0)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for f in range(frames):
+        frame(f)
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    lit = float((out[(frames - 1) & 1].view(H, W, 4)[:, :, :3].sum(dim=2) > 0).float().mean())
+    return {"workload": f"config 5 on one GPU: {frames} frames {W}x{H}, primary + shadow rays of two orbiting lights + "
+                        f"direct shading + PQ 8-bit colour, 1 000 000-triangle terrain",
+            "value": round(frames / wall, 2), "unit": "frames/s", "ms_per_frame": round(wall / frames * 1e3, 3),
+            "mpixels_per_s": round(frames * W * H / wall / 1e6, 1), "payload_bytes_per_frame": W * H * 4,
+            "lit_pixels": round(lit, 3)}
 
 
 def run_config4(rtg, torch, ctx, dev, launches=3):
@@ -177,6 +279,11 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="ctx option key=value (e.g. tri_min=16)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the configuration 4 record")
+    ap.add_argument("--no-c3", action="store_true", help="skip the configuration 3 record")
+    ap.add_argument("--no-c5", action="store_true", help="skip the configuration 5 record")
+    ap.add_argument("--no-configs", action="store_true", help="config 2 only: skip the records of configurations 3, 4 and 5")
+    ap.add_argument("--gather-timeout", type=float, default=90.0,
+                    help="with a gather: seconds the first warm-up step's gather may take before the run gives up")
     ap.add_argument("--grid", type=str, default=None, help="NXxNY quads (default 1000x500)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="frames in flight per GPU: that many contexts (one stream each) take the frames in turn")
@@ -196,6 +303,8 @@ def main():
     ap.add_argument("--gather", choices=["native", "torch"], default="native",
                     help="native: rtg_gather_tiles behind the C ABI (RCCL send/recv); torch: torch.distributed.gather")
     args = ap.parse_args()
+    if args.no_configs:
+        args.no_c3 = args.no_c4 = args.no_c5 = True
 
     import torch
     import torch.distributed as dist
@@ -285,15 +394,20 @@ def main():
                 else:
                     comm = rtg.Comm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()) if world > 1 else None)
                 gather_kind = "rtg_gather_tiles (RCCL send/recv behind the C ABI)" + (", one rank sending to itself" if world == 1 and args.loopback else "")
-            except Exception as e:                    # noqa: BLE001 -- reported in the JSON line, not hidden
-                gather_kind = f"torch.distributed.gather (rtg_comm_create failed: {e})"
-            if world > 1:                             # every rank must take the same path
-                ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+            except Exception as e:                    # noqa: BLE001 -- said on stderr; the run ends below
+                print(f"rank {rank}: the native communicator could not be created: {e}", file=sys.stderr, flush=True)
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+            if world > 1:                             # every rank learns of a failure anywhere and leaves together
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok.item()) == 0 and comm is not None:
+            if int(ok.item()) == 0:
+                # measuring another gather than the one asked for would change what the line means: no fallback
+                print(f"rank {rank}: no native gather on every rank; ask for the torch path with --gather torch",
+                      file=sys.stderr, flush=True)
+                if comm is not None:
                     comm.close()
-                    comm = None
-                    gather_kind = "torch.distributed.gather (rtg_comm_create failed on another rank)"
+                if world > 1:
+                    dist.destroy_process_group()
+                sys.exit(3)
         else:
             gather_kind = "torch.distributed.gather"
         pieces = shard.frame_pieces(world, frame_bytes)
@@ -320,13 +434,20 @@ def main():
             hits = hits_of[0][0]
             gather_kind += ", the root's own frames traced in place"
 
-    def step(i, ev=None):
+    def step(i, ev=None, probe=None):
+        """One frame.  `ev`: timing events around the traversal call; `probe` (with a gather): four more timing events
+        -- the traversal stream before and after its wait for the hit buffer's previous gather, the gather's stream
+        before and after the gather."""
         frame = i * world + rank
         k = i % inflight                              # the context that takes this frame
         b = (i // inflight) % n_buf if use_dist else 0
         st = streams[k]
         if use_dist:
+            if probe is not None:
+                probe[0].record(st)
             st.wait_event(gathered[k][b])             # the hit buffer is free once its previous gather has finished
+            if probe is not None:
+                probe[1].record(st)
         if ev is not None:
             ev[0].record(st)
         scenes[k].render_primary_raw(frame_view(rtg, frame), WIDTH, HEIGHT, tile, hits_of[k][b].data_ptr())
@@ -335,23 +456,45 @@ def main():
         if use_dist:
             rendered[k][b].record(st)
             comm_stream.wait_event(rendered[k][b])
+            if probe is not None:
+                probe[2].record(comm_stream)
             if comm is not None:                      # gather of the finished framebuffers to rank 0
                 comm.gather(0, hits_of[k][b].data_ptr(), recv[k][b].data_ptr() if rank == 0 else None, pieces,
                             stream_handle=comm_stream.cuda_stream)
             else:
                 with torch.cuda.stream(comm_stream):
                     shard.gather_to_root(hits_of[k][b], sizes, dst=0, out=recv[k][b])
+            if probe is not None:
+                probe[3].record(comm_stream)
             gathered[k][b].record(comm_stream)
 
     for i in range(args.warmup):
         step(i)
+        if use_dist and i == 0:
+            # The first gather is where a transport that cannot be set up shows (the connections between the ranks
+            # are made on first use): it gets a bounded wait, polled from the host, instead of the device-wide
+            # synchronize below, which would never return.  What is pending is said before the process leaves.
+            deadline = time.time() + args.gather_timeout
+            while not gathered[0][0].query():
+                if time.time() > deadline:
+                    print(f"rank {rank}: the first gather ({gather_kind}; {len(pieces)} pieces of {frame_bytes} bytes, "
+                          f"{world} ranks) has not completed after {args.gather_timeout:.0f} s; traversal of the frame "
+                          f"{'finished' if rendered[0][0].query() else 'not finished either'}; giving up",
+                          file=sys.stderr, flush=True)
+                    os._exit(4)
+                time.sleep(0.01)
+    # one untimed window of the timed windows' size: clocks and caches settle (the first window otherwise reads
+    # 2-4 % low whatever --warmup is)
+    for i in range(args.steps):
+        step(args.warmup + i)
+    settle_steps = args.steps
     # The kernel's duration for the roofline: HIP events that the launch itself fills with its execution window
     # (the dispatch's own begin and end timestamps -- what rocprofv3 reports per dispatch).  Events recorded around the call
     # would also count the time a launch waits in its stream's queue while the previous frame still owns the GPU.
     timed_kernels = args.traversal in (-1, 2)
     n_windows = max(1, args.windows)
-    window_s, window_kernel_ms = [], []
-    done = args.warmup
+    window_s, window_kernel_ms, window_gather = [], [], []
+    done = args.warmup + settle_steps
     for w_ in range(n_windows):
         if timed_kernels:
             torch.cuda.synchronize(dev)
@@ -359,12 +502,13 @@ def main():
                 c.set_option("time_kernels", 2)
                 c.kernel_time()
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        probes = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)] if use_dist else None
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(done + i, events[i])
+            step(done + i, events[i], probes[i] if probes else None)
         torch.cuda.synchronize(dev)                   # every stream: every frame rendered and gathered
         if use_dist:
             dist.barrier()
@@ -383,9 +527,35 @@ def main():
             kernel_ms = sum(ms for ms, _ in windows) / args.steps
         window_s.append(elapsed)
         window_kernel_ms.append(kernel_ms)
+        if use_dist:                                  # this rank's waits and gathers, per step
+            window_gather.append((float(np.mean([p[0].elapsed_time(p[1]) for p in probes])),
+                                  float(np.mean([p[2].elapsed_time(p[3]) for p in probes]))))
     order = np.argsort(window_s)
     mid = int(order[(n_windows - 1) // 2])            # the median window (the lower one of an even count)
     elapsed, kernel_ms = window_s[mid], window_kernel_ms[mid]
+    gather_rec = None
+    if use_dist:
+        # every rank's wait for a free hit buffer and its gather's duration in the median window, collected on rank 0
+        mine = torch.tensor(list(window_gather[mid]), dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)] if world > 1 else [mine]
+        if world > 1:
+            dist.all_gather(every, mine)
+        waits = [float(t[0].item()) for t in every]
+        durs = [float(t[1].item()) for t in every]
+        ranks_info = comm.info() if comm is not None else (world, rank, None)
+        sent = sum(p[3] for p in pieces if p[0] != 0)          # bytes that cross a link per step
+        root_ms = durs[0]
+        gather_rec = {
+            "kind": gather_kind, "ranks": world, "rccl_ranks": ranks_info[2],
+            "bytes_per_step_per_rank": frame_bytes, "bytes_into_root_per_step": sent,
+            "gather_ms_per_step_by_rank": [round(v, 4) for v in durs],
+            "wait_for_hit_buffer_ms_per_step_by_rank": [round(v, 4) for v in waits],
+            "gbs_per_sending_rank": [None] + [round(frame_bytes / (v * 1e-3) / 1e9, 1) if v > 0 else None for v in durs[1:]],
+            "gbs_into_root": round(sent / (root_ms * 1e-3) / 1e9, 1) if (root_ms > 0 and sent) else None,
+            "link_budget": "one xGMI link per peer, about 153 GB/s both ways together, so about 77 GB/s one way (the "
+                           f"platform's nominal figure, not measured here): a sending rank moves {frame_bytes / 1e6:.1f} MB "
+                           "per step over its link to the root, the root takes (ranks - 1) such frames over as many links",
+        }
 
     if rank == 0:
         # node visits and algorithmic bytes of one launch, from the kernel's own counting build on frame 0
@@ -434,14 +604,21 @@ def main():
         if roof["gather"]["peak"]:
             roof["gather"]["frac_timed_region"] = round(roof["gather"]["achieved_timed_region"] / roof["gather"]["peak"], 4)
         configs = None
-        if world == 1 and not args.no_c4 and default_run:
+        if world == 1 and default_run and not args.force_dist:
             torch.cuda.set_stream(stream)
-            configs = {"c4": run_config4(rtg, torch, ctx, dev)}
+            configs = {}
+            if not args.no_c5:
+                configs["c5"] = run_config5(rtg, torch, ctx, dev, scene)
+            if not args.no_c3:
+                configs["c3"] = run_config3(rtg, torch, ctx, dev)
+            if not args.no_c4:
+                configs["c4"] = run_config4(rtg, torch, ctx, dev)
+            configs = configs or None
         out = {
             "metric": "Mrays/s, 1M-tri BVH scene", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "windows": n_windows, "windows_mrays": window_mrays,
+            "windows": n_windows, "settle_steps": settle_steps, "windows_mrays": window_mrays,
             "spread": round((max(window_mrays) - min(window_mrays)) / float(np.median(window_mrays)), 4),
             "config": {"workload": f"config 2: {2 * nx * ny}-triangle terrain BVH ({bvh.n_nodes} nodes, depth {bvh.depth}), "
                                    f"{WIDTH}x{HEIGHT} primary rays per step per GPU, closest-hit ids",
@@ -454,6 +631,8 @@ def main():
             "cpu_baseline": cpu,
             "configs": configs,
         }
+        if gather_rec is not None:
+            out["gather"] = gather_rec
         print(json.dumps(out), file=json_out, flush=True)
     if use_dist:
         dist.barrier()

@@ -62,7 +62,7 @@ def test_committed_bench_record_follows_from_the_committed_evidence(workload, n_
 
 
 def test_launch_duration_agrees_with_the_rocprofv3_summary_of_the_same_command():
-    """kernel_stats.csv is `rocprofv3 --kernel-trace --stats` over `python3 bench.py --no-cpu --no-c4`;
+    """kernel_stats.csv is `rocprofv3 --kernel-trace --stats` over `python3 bench.py --no-cpu --no-configs`;
     bench_under_rocprof.json is the line that very run printed.  The duration bench.py takes from the launches' own
     events and the profiler's average over the same launches (warm-up included) agree within 2 %."""
     import csv

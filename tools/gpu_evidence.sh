@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
 timeout -k 10 120 ./tools/micro/tcp_gather > "$OUT/tcp_gather.txt" 2>&1 &&
 timeout -k 10 400 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" &&
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu --no-c4 > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err") &&
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu --no-configs > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err") &&
 tools/prof_pmc.sh "$D/pmc" &&
 python tools/pmc_summary.py "$OUT/pmc" k_trace_phased > "$OUT/pmc_summary.txt" &&
 tools/prof_pmc.sh "$D/pmc_c4" tools/c4_prof.py 1 &&

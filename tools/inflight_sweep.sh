@@ -5,7 +5,7 @@ set -u
 out=${1:-gpurun_out/inflight}
 mkdir -p "$out"
 for k in 1 2 3 4; do
-  timeout -k 10 120 python bench.py --no-cpu --no-c4 --inflight $k > "$out/inflight$k.json" 2> "$out/inflight$k.err" || exit 1
+  timeout -k 10 120 python bench.py --no-cpu --no-configs --inflight $k > "$out/inflight$k.json" 2> "$out/inflight$k.err" || exit 1
   python - "$out/inflight$k.json" $k <<'PY'
 import json, sys
 r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects rocprofv3 counters for one kernel, one --pmc pass per run (the tool does not split counters over
 # passes).  Usage: tools/prof_pmc.sh <out_dir_under_gpurun_out> [script relative to the repo root] [script args...]
-# Default script: bench.py --steps 3 --warmup 1 --windows 1 --no-cpu --no-c4.  Run on the GPU box from the repo root.
+# Default script: bench.py --steps 3 --warmup 1 --windows 1 --no-cpu --no-configs.  Run on the GPU box from the repo root.
 set -u
 OUT="$GRAFT_REPO_ROOT/gpurun_out/$1"; shift
-if [ $# -gt 0 ]; then SCRIPT="$1"; shift; ARGS=("$@"); else SCRIPT="bench.py"; ARGS=(--steps 3 --warmup 1 --windows 1 --no-cpu --no-c4); fi
+if [ $# -gt 0 ]; then SCRIPT="$1"; shift; ARGS=("$@"); else SCRIPT="bench.py"; ARGS=(--steps 3 --warmup 1 --windows 1 --no-cpu --no-configs); fi
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() {
