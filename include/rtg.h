@@ -249,6 +249,11 @@ int rtg_ctx_synchronize(rtg_ctx *ctx);
  *   "sort_rays" 2 = rtg_trace (traversal 2) puts the batch into coherence order on the device first (key = direction
  *                   octant | 30-bit Morton code of the origin; one radix sort), traces it and returns the answers in
  *                   the caller's order; 1 = off (default: for one trace of a batch the sort costs more than it saves)
+ *   "photon_trig" 2 = the photon pass takes the cosine and sine of every direction's zenith with the GPU's own
+ *                     routines (ZenithY::into_normal, src/geo/sphere.rs:29-34): directions may then be device memory
+ *                     and nothing but 16 bytes per direction crosses PCIe; photon positions agree with host mode to
+ *                     about 1e-15 relative, not bit for bit (the last place of sin / cos differs between libraries,
+ *                     as it does between the platforms the reference runs on); 1 = host libm (default)
  *   "time_kernels" 2 = record each persistent-kernel launch's execution window (rtg_ctx_kernel_time), 1 = off */
 int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value);
 /* With option "time_kernels" = 2 every persistent-kernel launch behind rtg_render_primary / rtg_trace records its
@@ -413,6 +418,14 @@ int rtg_photon_map_create(rtg_ctx *ctx, const rtg_photon *photons, uint64_t n_ph
  * order rtg_photons_emit would have written them).  *n_photons (may be NULL) receives the number of photons. */
 int rtg_photon_map_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const double *dirs2,
                         uint64_t count_per_light, uint32_t max_depth, rtg_photon_map **out, uint64_t *n_photons);
+/* The same with the directions made on the GPU as well: `Sphere::fibonacci_sphere(photon_count, rng)` per light
+ * (src/geo/sphere.rs:52-80, src/render/renderer.rs:116-118), batch by batch, so that nothing of the pass crosses
+ * PCIe.  The reference draws the per-direction jitter from an entropy-seeded generator (renderer.rs:112); here it
+ * comes from a SplitMix64 stream seeded with `seed` + l * 0x9E3779B97F4A7C15 for light l, direction k taking draws
+ * 2k and 2k + 1 -- the (zenith, y) pairs are bit for bit those the host generator of this build makes from the same
+ * seed, and their cosines and sines are the GPU's (as with option "photon_trig" = 2). */
+int rtg_photon_map_emit_fibonacci(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, uint64_t count_per_light,
+                                  uint64_t seed, uint32_t max_depth, rtg_photon_map **out, uint64_t *n_photons);
 void rtg_photon_map_destroy(rtg_photon_map *map);
 
 /* `KdTree::nearest(&p, k)` (src/tree/kd_tree.rs:115-154) for a batch of query points: out_index[q * k + j] is the

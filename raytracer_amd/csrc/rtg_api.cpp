@@ -577,6 +577,10 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) try {
         ctx->tune.stats = value > 1 ? 1u : 0u;   // 2 = on, 1 = off (0 is rejected above as out of range)
         return RTG_OK;
     }
+    if (std::strcmp(key, "photon_trig") == 0) {
+        ctx->photon_trig_device = value > 1;     // 2 = device, 1 = host libm
+        return RTG_OK;
+    }
     if (std::strcmp(key, "comm_loopback") == 0) {
         ctx->comm_loopback = value > 1;          // 2 = on, 1 = off
         return RTG_OK;

@@ -33,6 +33,9 @@ struct rtg_ctx {
     // option "comm_loopback": a communicator created on this context is a real RCCL communicator even with one rank,
     // and the root's own pieces travel by ncclSend / ncclRecv to itself (the several-rank machinery on one GPU)
     bool comm_loopback = false;
+    // option "photon_trig": the photon directions' cosines and sines come from the device's own routines instead of
+    // the host's libm (ZenithY::into_normal, src/geo/sphere.rs:29-34)
+    bool photon_trig_device = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, idle_events;
     // rtg_render_frame renders a frame of an opaque scene as two row bands on two streams (option "frame_bands"):
     // `side` is an internal context (own stream and scratch) for the second band, joined back by events

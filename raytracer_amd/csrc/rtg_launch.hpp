@@ -138,6 +138,10 @@ hipError_t build_kd_device(hipStream_t stream, const rtg_photon *photons, uint32
 // zenith, y per direction, device memory).
 hipError_t launch_photon_rays(hipStream_t stream, const double *staged, uint32_t n, const rtg_light *lights, uint64_t first_ray,
                               uint64_t count_per_light, double *rays6, double *dirs2);
+hipError_t launch_photon_rays_trig(hipStream_t stream, const double *dirs2_in, uint32_t n, const rtg_light *lights,
+                                   uint64_t first_ray, uint64_t count_per_light, double *rays6, double *dirs2);
+hipError_t launch_photon_rays_fibonacci(hipStream_t stream, uint32_t n, const rtg_light *lights, uint64_t first_ray,
+                                        uint64_t count_per_light, uint64_t seed, double *rays6, double *dirs2);
 // Photons of one batch of path records: flags + exclusive scan (offsets[i] = photons before path i) + records
 // written at out[offsets[i]] while that is below `room`.
 size_t photon_scan_temp_bytes(uint32_t n);

@@ -447,6 +447,69 @@ __global__ __launch_bounds__(256) void k_photon_rays(const double *__restrict__ 
     w[2] = make_double2(zy.y, cs.y * radius);
     reinterpret_cast<double2 *>(dirs2)[i] = zy;
 }
+// The same with the cosine and sine taken here (option "photon_trig" = device): `dirs2_in` holds zenith, y.
+__global__ __launch_bounds__(256) void k_photon_rays_trig(const double *__restrict__ dirs2_in, uint32_t n,
+                                                          const rtg_light *__restrict__ lights, uint64_t first_ray,
+                                                          uint64_t count_per_light, double *__restrict__ rays6,
+                                                          double *__restrict__ dirs2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double2 zy = reinterpret_cast<const double2 *>(dirs2_in)[i];
+    const rtg_light &light = lights[(first_ray + i) / count_per_light];
+    const double radius = __builtin_sqrt(1.0 - zy.y * zy.y);
+    const double c = cos(zy.x), s = sin(zy.x);
+    double2 *w = reinterpret_cast<double2 *>(rays6 + (size_t)i * 6);
+    w[0] = make_double2(light.position[0], light.position[1]);
+    w[1] = make_double2(light.position[2], c * radius);
+    w[2] = make_double2(zy.y, s * radius);
+    reinterpret_cast<double2 *>(dirs2)[i] = zy;
+}
+// The same for directions made here: Sphere::fibonacci_sphere (src/geo/sphere.rs:52-80) for ray `first_ray + i` of the
+// pass, i.e. direction k = ray mod count_per_light of light ray / count_per_light, with the two draws per direction
+// taken from a SplitMix64 stream seeded per light (seed + l * gamma; direction k uses draws 2k and 2k + 1, whose
+// state is the seed advanced 2k times) -- the stream and the arithmetic of the host library's generator, so both
+// make the same (zenith, y) bits: the remainder is the exact one (one fused multiply-add after the rounded
+// quotient, corrected by at most one step), everything else a single rounded operation.
+__device__ __forceinline__ uint64_t splitmix64_next(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_photon_rays_fibonacci(uint32_t n, const rtg_light *__restrict__ lights, uint64_t first_ray,
+                                                               uint64_t count_per_light, uint64_t seed, double *__restrict__ rays6,
+                                                               double *__restrict__ dirs2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t ray = first_ray + i, l = ray / count_per_light, k = ray - l * count_per_light;
+    const double phi = kPi * (3.0 - __builtin_sqrt(5.0));
+    const double d = 2.0 * kPi / phi;
+    const double dydi = 2.0 / ((double)count_per_light + d);
+    const double dydj = dydi * d;
+    uint64_t s = seed + l * 0x9E3779B97F4A7C15ull + 2 * k * 0x9E3779B97F4A7C15ull;
+    const double u = (double)(splitmix64_next(s) >> 11) * (1.0 / 9007199254740992.0);
+    const double v = (double)(splitmix64_next(s) >> 11) * (1.0 / 9007199254740992.0);
+    const double fi = (double)k + u;
+    const double x = phi * fi, y2pi = 2.0 * kPi;
+    double q = __builtin_floor(x / y2pi);
+    double zenith = __builtin_fma(-q, y2pi, x);
+    if (zenith < 0.0) {
+        q -= 1.0;
+        zenith = __builtin_fma(-q, y2pi, x);
+    } else if (zenith >= y2pi) {
+        q += 1.0;
+        zenith = __builtin_fma(-q, y2pi, x);
+    }
+    const double y = -1.0 + dydi * fi + dydj * v;
+    const rtg_light &light = lights[l];
+    const double radius = __builtin_sqrt(1.0 - y * y);
+    const double c = cos(zenith), sn = sin(zenith);
+    double2 *w = reinterpret_cast<double2 *>(rays6 + (size_t)i * 6);
+    w[0] = make_double2(light.position[0], light.position[1]);
+    w[1] = make_double2(light.position[2], c * radius);
+    w[2] = make_double2(y, sn * radius);
+    reinterpret_cast<double2 *>(dirs2)[i] = make_double2(zenith, y);
+}
 __global__ __launch_bounds__(256) void k_photon_flags(const rtg_path *__restrict__ paths, uint32_t n, uint32_t *__restrict__ flags) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flags[i] = paths[i].depth >= 1 ? 1u : 0u;      // `if path.modes.len() == 0 { return None }`
@@ -806,6 +869,20 @@ hipError_t launch_photon_rays(hipStream_t stream, const double *staged, uint32_t
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_photon_rays, dim3((n + 255) / 256), dim3(256), 0, stream, staged, n, lights, first_ray, count_per_light, rays6,
                        dirs2);
+    return hipGetLastError();
+}
+hipError_t launch_photon_rays_trig(hipStream_t stream, const double *dirs2_in, uint32_t n, const rtg_light *lights,
+                                   uint64_t first_ray, uint64_t count_per_light, double *rays6, double *dirs2) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_photon_rays_trig, dim3((n + 255) / 256), dim3(256), 0, stream, dirs2_in, n, lights, first_ray,
+                       count_per_light, rays6, dirs2);
+    return hipGetLastError();
+}
+hipError_t launch_photon_rays_fibonacci(hipStream_t stream, uint32_t n, const rtg_light *lights, uint64_t first_ray,
+                                        uint64_t count_per_light, uint64_t seed, double *rays6, double *dirs2) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_photon_rays_fibonacci, dim3((n + 255) / 256), dim3(256), 0, stream, n, lights, first_ray, count_per_light,
+                       seed, rays6, dirs2);
     return hipGetLastError();
 }
 hipError_t launch_camera_rays(hipStream_t stream, const rtg_view &view, uint32_t width, uint32_t height, rtg_rect tile, double *rays6) {

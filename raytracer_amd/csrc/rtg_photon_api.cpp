@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <cstring>
 #include <limits>
 #include <new>
 #include <system_error>
@@ -143,16 +144,19 @@ int check_emit_args(rtg_ctx *ctx, const rtg_light *lights, uint32_t n_lights, co
     if (max_depth < 1 || max_depth > 4) return api_fail(ctx, RTG_E_INVALID, "photon pass: max_depth must be 1..4");
     if ((uint64_t)n_lights * count_per_light == 0) return RTG_OK;
     if (!lights || !dirs2) return api_fail(ctx, RTG_E_INVALID, "photon pass: lights / dirs2 is null");
-    if (api_is_device_pointer(lights) || api_is_device_pointer(dirs2))
-        return api_fail(ctx, RTG_E_INVALID, "photon pass: lights and dirs2 are host memory (the directions' sin / cos are taken on the host)");
+    if (api_is_device_pointer(lights)) return api_fail(ctx, RTG_E_INVALID, "photon pass: lights is host memory");
+    if (api_is_device_pointer(dirs2) && !ctx->photon_trig_device)
+        return api_fail(ctx, RTG_E_INVALID, "photon pass: dirs2 is host memory (the directions' sin / cos are taken on the host; "
+                                            "option photon_trig = 2 takes them on the device and accepts device memory)");
     if (count_per_light > (1ull << 40) || (uint64_t)n_lights * count_per_light > (1ull << 40))
         return api_fail(ctx, RTG_E_LIMIT, "photon pass: too many directions");
     return RTG_OK;
 }
 
 // renderer.rs:116-138 for checked arguments; *n_total receives the number of photons the pass makes.
+// `fibonacci_seed` (dirs2 == nullptr): the directions are Sphere::fibonacci_sphere's, made on the device batch by batch.
 int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, const double *dirs2, uint64_t count_per_light,
-                 uint32_t max_depth, PhotonSink &sink, uint64_t *n_total) {
+                 uint32_t max_depth, PhotonSink &sink, uint64_t *n_total, const uint64_t *fibonacci_seed = nullptr) {
     rtg_ctx *ctx = scene->ctx;
     int rc;
     *n_total = 0;
@@ -173,10 +177,25 @@ int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, c
             if (p) (void)hipHostFree(p);
         }
     } staging[2];
-    const size_t batch_doubles = (size_t)std::min(batch, n_rays) * 4;
-    HIP_TRY(ctx, hipHostMalloc((void **)&staging[0].p, batch_doubles * sizeof(double), hipHostMallocDefault));
-    if (n_rays > batch) HIP_TRY(ctx, hipHostMalloc((void **)&staging[1].p, batch_doubles * sizeof(double), hipHostMallocDefault));
+    // With the option "photon_trig" on the device, only zenith and y travel (16 bytes per direction, staged through the
+    // same pinned buffers; nothing at all when the caller's directions are device memory) and the kernel that finishes
+    // the rays takes cosine and sine itself.
+    const bool trig_device = ctx->photon_trig_device || fibonacci_seed != nullptr;
+    const bool dirs_on_device = fibonacci_seed != nullptr || (trig_device && api_is_device_pointer(dirs2));
+    const size_t per_dir = trig_device ? 2 : 4;
+    const size_t batch_doubles = (size_t)std::min(batch, n_rays) * per_dir;
+    if (!dirs_on_device) {
+        HIP_TRY(ctx, hipHostMalloc((void **)&staging[0].p, batch_doubles * sizeof(double), hipHostMallocDefault));
+        if (n_rays > batch) HIP_TRY(ctx, hipHostMalloc((void **)&staging[1].p, batch_doubles * sizeof(double), hipHostMallocDefault));
+    }
     auto make_batch = [&](uint64_t first, double *dst) {
+        if (dirs_on_device) return;
+        if (trig_device) {
+            api_parallel_ranges((size_t)std::min(batch, n_rays - first), 1 << 16, [=](size_t begin, size_t end) {
+                std::memcpy(dst + begin * 2, dirs2 + (first + begin) * 2, (end - begin) * 2 * sizeof(double));
+            });
+            return;
+        }
         api_parallel_ranges((size_t)std::min(batch, n_rays - first), 4096, [=](size_t begin, size_t end) {
             for (size_t i = begin; i < end; i++) {
                 const double zenith = dirs2[(first + i) * 2], y = dirs2[(first + i) * 2 + 1];
@@ -200,7 +219,7 @@ int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, c
         const uint64_t m = std::min(batch, n_rays - first);
         const double *staged = staging[b & 1].p;
         Joined ahead;                                        // joined at the end of the iteration, however it ends
-        if (first + batch < n_rays) {
+        if (first + batch < n_rays && !dirs_on_device) {
             double *dst = staging[(b + 1) & 1].p;
             const uint64_t next_first = first + batch;
             try {
@@ -211,12 +230,20 @@ int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, c
         }
         void *d_paths = nullptr, *d_staged = nullptr, *d_rays = nullptr, *d_dirs = nullptr;
         if ((rc = api_scratch(ctx, "photon_paths", (size_t)(m * per_ray) * sizeof(rtg_path), &d_paths)) != RTG_OK) return rc;
-        if ((rc = api_scratch(ctx, "photon_staged", (size_t)m * 4 * sizeof(double), &d_staged)) != RTG_OK) return rc;
+        if (!dirs_on_device && (rc = api_scratch(ctx, "photon_staged", (size_t)m * per_dir * sizeof(double), &d_staged)) != RTG_OK) return rc;
         if ((rc = api_scratch(ctx, "photon_rays", (size_t)m * 6 * sizeof(double), &d_rays)) != RTG_OK) return rc;
         if ((rc = api_scratch(ctx, "photon_dirs", (size_t)m * 2 * sizeof(double), &d_dirs)) != RTG_OK) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(d_staged, staged, (size_t)m * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, launch_photon_rays(ctx->stream, (const double *)d_staged, (uint32_t)m, (const rtg_light *)d_lights, first,
-                                        count_per_light, (double *)d_rays, (double *)d_dirs));
+        if (!dirs_on_device)
+            HIP_TRY(ctx, hipMemcpyAsync(d_staged, staged, (size_t)m * per_dir * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if (fibonacci_seed)
+            HIP_TRY(ctx, launch_photon_rays_fibonacci(ctx->stream, (uint32_t)m, (const rtg_light *)d_lights, first, count_per_light,
+                                                      *fibonacci_seed, (double *)d_rays, (double *)d_dirs));
+        else if (trig_device)
+            HIP_TRY(ctx, launch_photon_rays_trig(ctx->stream, dirs_on_device ? dirs2 + first * 2 : (const double *)d_staged, (uint32_t)m,
+                                                 (const rtg_light *)d_lights, first, count_per_light, (double *)d_rays, (double *)d_dirs));
+        else
+            HIP_TRY(ctx, launch_photon_rays(ctx->stream, (const double *)d_staged, (uint32_t)m, (const rtg_light *)d_lights, first,
+                                            count_per_light, (double *)d_rays, (double *)d_dirs));
         uint64_t n_paths = 0;
         if ((rc = rtg_trace_paths(scene, (const double *)d_rays, m, max_depth, (rtg_path *)d_paths, m * per_ray, &n_paths)) != RTG_OK)
             return rc;
@@ -383,6 +410,35 @@ int rtg_photon_map_emit(rtg_scene *scene, const rtg_light *lights, uint32_t n_li
     return RTG_OK;
 } catch (...) {
     return api_caught(scene ? scene->ctx : nullptr, "rtg_photon_map_emit");
+}
+
+int rtg_photon_map_emit_fibonacci(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, uint64_t count_per_light,
+                                  uint64_t seed, uint32_t max_depth, rtg_photon_map **out, uint64_t *n_photons) try {
+    int rc = api_bind_scene(scene);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = scene->ctx;
+    if (!out) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_emit_fibonacci: out is null");
+    *out = nullptr;
+    if (n_photons) *n_photons = 0;
+    if (max_depth < 1 || max_depth > 4) return api_fail(ctx, RTG_E_INVALID, "photon pass: max_depth must be 1..4");
+    if ((uint64_t)n_lights * count_per_light != 0) {
+        if (!lights || api_is_device_pointer(lights)) return api_fail(ctx, RTG_E_INVALID, "photon pass: lights is null or not host memory");
+        if (count_per_light > (1ull << 40) || (uint64_t)n_lights * count_per_light > (1ull << 40))
+            return api_fail(ctx, RTG_E_LIMIT, "photon pass: too many directions");
+    }
+    PhotonSink sink;
+    sink.grow = true;
+    uint64_t total = 0;
+    if ((rc = emit_photons(scene, lights, n_lights, nullptr, count_per_light, max_depth, sink, &total, &seed)) != RTG_OK) return rc;
+    if (total >= (1ull << 31))
+        return api_fail(ctx, RTG_E_LIMIT, "rtg_photon_map_emit_fibonacci: %llu photons, at most 2^31 - 1", (unsigned long long)total);
+    void *d_photons = total ? sink.held : nullptr;       // map_over owns the records from here on
+    if (total) sink.held = nullptr;
+    if ((rc = map_over(ctx, d_photons, total, out)) != RTG_OK) return rc;
+    if (n_photons) *n_photons = total;
+    return RTG_OK;
+} catch (...) {
+    return api_caught(scene ? scene->ctx : nullptr, "rtg_photon_map_emit_fibonacci");
 }
 
 void rtg_photon_map_destroy(rtg_photon_map *map) {

@@ -121,8 +121,8 @@ int rth_render_scene_builder(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32
     return RTG_E_INTERNAL;
 }
 int rth_render_scene_builder_photons(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32_t height, uint32_t max_depth,
-                                     uint64_t photon_count, uint64_t seed, double *out_rgb, uint64_t *n_photons,
-                                     double seconds[3]) try {
+                                     uint64_t photon_count, uint64_t seed, int photons_on_host, double *out_rgb,
+                                     uint64_t *n_photons, double seconds[3]) try {
     rt::SceneBuilder sb;
     sb.time = time;
     rt::Scene scene = sb.scene();
@@ -132,6 +132,7 @@ int rth_render_scene_builder_photons(rtg_ctx *ctx, uint64_t time, uint32_t width
     rt::Renderer r(ctx, std::move(scene));
     r.max_depth = max_depth;
     r.photon_pass = true;
+    r.photons_on_host = photons_on_host != 0;
     r.seed = seed;
     int rc = r.render();
     if (n_photons) *n_photons = r.photons();

@@ -46,10 +46,11 @@ int rth_render_scene_builder(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32
                              double *out_rgb, rtg_hit *out_hits);
 /* The same with the photon pass of Renderer::render (src/render/renderer.rs:116-140): `photon_count` Fibonacci
  * directions per light from `seed` (the reference seeds from entropy), the photon map, and the pixel pass with the
- * photon term.  seconds[3] (may be NULL): directions, photon pass + k-d tree, pixel pass. */
+ * photon term.  photons_on_host != 0: directions and their sin / cos on the host (the CPU renderer's photons bit for
+ * bit); 0: the whole pass on the GPU.  seconds[3] (may be NULL): directions, photon pass + k-d tree, pixel pass. */
 int rth_render_scene_builder_photons(rtg_ctx *ctx, uint64_t time, uint32_t width, uint32_t height, uint32_t max_depth,
-                                     uint64_t photon_count, uint64_t seed, double *out_rgb, uint64_t *n_photons,
-                                     double seconds[3]);
+                                     uint64_t photon_count, uint64_t seed, int photons_on_host, double *out_rgb,
+                                     uint64_t *n_photons, double seconds[3]);
 /* Radiance .hdr bytes of an RGB double image as ImageBuilder::to_hdr writes them (src/render/image.rs:44-71);
  * returns the byte count; called with out == NULL it returns an upper bound to size the buffer with. */
 uint64_t rth_to_hdr(const double *rgb, uint32_t width, uint32_t height, uint8_t *out, uint64_t cap);

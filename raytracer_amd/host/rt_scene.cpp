@@ -232,19 +232,27 @@ int Renderer::render() {
     // renderer.rs:116-140: a Fibonacci sphere of directions per light, every path behind a specular bounce a photon,
     // the photons in a k-d tree
     auto t0 = std::chrono::steady_clock::now();
-    // not a vector: its elements would be zeroed by one thread first (320 MB at the reference's default counts), and
-    // the pages are better touched by the threads that fill them
-    std::unique_ptr<double[]> dirs(new double[lights.size() * (size_t)scene_.photon_count * 2]);
-    for (size_t l = 0; l < lights.size(); l++)
-        fibonacci_zenith_y(scene_.photon_count, seed + 0x9E3779B97F4A7C15ull * l, dirs.get() + l * (size_t)scene_.photon_count * 2);
-    seconds_dirs_ = since(t0);
-    t0 = std::chrono::steady_clock::now();
     if (photon_map_) {
         rtg_photon_map_destroy(photon_map_);
         photon_map_ = nullptr;
     }
-    int rc = rtg_photon_map_emit(gpu_scene_, lights.data(), (uint32_t)lights.size(), dirs.get(), scene_.photon_count, max_depth,
+    int rc;
+    if (photons_on_host) {
+        // not a vector: its elements would be zeroed by one thread first (320 MB at the reference's default counts),
+        // and the pages are better touched by the threads that fill them
+        std::unique_ptr<double[]> dirs(new double[lights.size() * (size_t)scene_.photon_count * 2]);
+        for (size_t l = 0; l < lights.size(); l++)
+            fibonacci_zenith_y(scene_.photon_count, seed + 0x9E3779B97F4A7C15ull * l, dirs.get() + l * (size_t)scene_.photon_count * 2);
+        seconds_dirs_ = since(t0);
+        t0 = std::chrono::steady_clock::now();
+        rc = rtg_photon_map_emit(gpu_scene_, lights.data(), (uint32_t)lights.size(), dirs.get(), scene_.photon_count, max_depth,
                                  &photon_map_, &n_photons_);
+    } else {
+        // the same directions (same seeds, same bits) made on the GPU batch by batch, their cosines and sines the GPU's
+        seconds_dirs_ = 0.0;
+        rc = rtg_photon_map_emit_fibonacci(gpu_scene_, lights.data(), (uint32_t)lights.size(), scene_.photon_count, seed, max_depth,
+                                           &photon_map_, &n_photons_);
+    }
     seconds_photons_ = since(t0);
     if (rc != RTG_OK) return rc;
     // renderer.rs:141-153: the pixel pass

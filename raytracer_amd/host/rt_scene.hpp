@@ -130,6 +130,9 @@ class Renderer {
     const char *error() const;
     uint32_t max_depth = 4;                       // renderer.rs:312
     bool photon_pass = false;
+    // true: the photon directions are made and turned into rays on the host (libm's sin / cos: bit for bit the
+    // CPU renderer's photons); false: all of the photon pass runs on the GPU (same directions, the GPU's sin / cos)
+    bool photons_on_host = false;
     uint64_t seed = 1;                            // stands for the entropy-seeded generator of renderer.rs:112
     uint64_t photons() const { return n_photons_; }
     // wall time of the last render's parts: directions (the caller's side in the reference), photon pass + k-d

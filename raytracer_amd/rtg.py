@@ -150,6 +150,8 @@ _sig(lib.rtg_render_frame, C.c_int, _vp, C.POINTER(View), _vp, C.c_uint32, C.c_u
 _sig(lib.rtg_photons_emit, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64))
 _sig(lib.rtg_photon_map_create, C.c_int, _vp, _vp, C.c_uint64, C.POINTER(_vp))
 _sig(lib.rtg_photon_map_emit, C.c_int, _vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.POINTER(_vp), C.POINTER(C.c_uint64))
+_sig(lib.rtg_photon_map_emit_fibonacci, C.c_int, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(_vp),
+     C.POINTER(C.c_uint64))
 _sig(lib.rtg_photon_map_destroy, None, _vp)
 _sig(lib.rtg_photon_map_nearest, C.c_int, _vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp)
 _sig(lib.rtg_render_frame_photons, C.c_int, _vp, C.POINTER(View), _vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_double,
@@ -181,8 +183,8 @@ _sig(host.rth_patch_terrain, None, C.c_uint32, C.c_uint32, C.c_uint64, C.c_doubl
 _sig(host.rth_transform_build, None, C.c_double, C.POINTER(C.c_double), C.POINTER(Transform))
 _sig(host.rth_scene_builder, None, C.c_uint64, C.POINTER(Object), C.POINTER(Light), C.POINTER(View))
 _sig(host.rth_render_scene_builder, C.c_int, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp)
-_sig(host.rth_render_scene_builder_photons, C.c_int, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _vp,
-     C.POINTER(C.c_uint64), _vp)
+_sig(host.rth_render_scene_builder_photons, C.c_int, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
+     C.c_int, _vp, C.POINTER(C.c_uint64), _vp)
 _sig(host.rth_to_hdr, C.c_uint64, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64)
 _sig(host.rth_images_tar, C.c_uint64, _vp, C.c_uint32, C.c_uint32, C.c_double, _vp, _vp, C.c_uint64)
 _sig(host.rth_render_images, C.c_int, _vp, C.POINTER(Object), C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_double),
@@ -818,12 +820,25 @@ class Scene:
                                                 C.byref(h), C.byref(count)))
         return PhotonMap(self.ctx, None, n=count.value, _handle=h)
 
-    def photons_emit_raw(self, lights, dirs2, out_ptr, capacity, max_depth=4):
-        """The photon pass into caller-chosen memory (host or device address of `capacity` records): photons made."""
+    def photon_map_fibonacci(self, lights, count_per_light, seed, max_depth=4):
+        """Sphere::fibonacci_sphere per light, the photon pass and KdTree::new, all on the GPU: a PhotonMap."""
         lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
-        dirs2 = np.ascontiguousarray(dirs2, dtype=np.float64).reshape(lights.shape[0], -1, 2)
+        h, count = _vp(), C.c_uint64()
+        self.ctx._check(lib.rtg_photon_map_emit_fibonacci(self._h, _ptr(lights), lights.shape[0], count_per_light, seed, max_depth,
+                                                          C.byref(h), C.byref(count)))
+        return PhotonMap(self.ctx, None, n=count.value, _handle=h)
+
+    def photons_emit_raw(self, lights, dirs2, out_ptr, capacity, max_depth=4):
+        """The photon pass into caller-chosen memory (host or device address of `capacity` records): photons made.
+        `dirs2` may be (device address, directions per light) when the context's option photon_trig is 2."""
+        lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+        if isinstance(dirs2, tuple):
+            dirs_ptr, per_light = _ptr(dirs2[0]), int(dirs2[1])
+        else:
+            dirs2 = np.ascontiguousarray(dirs2, dtype=np.float64).reshape(lights.shape[0], -1, 2)
+            dirs_ptr, per_light = _ptr(dirs2), dirs2.shape[1]
         count = C.c_uint64()
-        self.ctx._check(lib.rtg_photons_emit(self._h, _ptr(lights), lights.shape[0], _ptr(dirs2), dirs2.shape[1], max_depth,
+        self.ctx._check(lib.rtg_photons_emit(self._h, _ptr(lights), lights.shape[0], dirs_ptr, per_light, max_depth,
                                              _ptr(out_ptr) if capacity else None, capacity, C.byref(count)))
         return count.value
 
@@ -885,13 +900,15 @@ def render_scene_builder(ctx, time, width, height, max_depth=4):
     return rgb, hits
 
 
-def render_scene_builder_photons(ctx, time, width, height, photon_count, seed=1, max_depth=4):
-    """Renderer::render with its photon pass at width x height: (rgb, photons made, seconds of the three parts)."""
+def render_scene_builder_photons(ctx, time, width, height, photon_count, seed=1, max_depth=4, photons_on_host=False):
+    """Renderer::render with its photon pass at width x height: (rgb, photons made, seconds of the three parts).
+    photons_on_host: directions and their sin / cos on the host (the oracle's photons bit for bit) instead of the
+    whole pass on the GPU."""
     rgb = np.empty((height * width, 3), dtype=np.float64)
     n = C.c_uint64()
     seconds = (C.c_double * 3)()
-    ctx._check(host.rth_render_scene_builder_photons(ctx._h, time, width, height, max_depth, photon_count, seed, _ptr(rgb),
-                                                     C.byref(n), seconds))
+    ctx._check(host.rth_render_scene_builder_photons(ctx._h, time, width, height, max_depth, photon_count, seed,
+                                                     1 if photons_on_host else 0, _ptr(rgb), C.byref(n), seconds))
     return rgb, n.value, tuple(seconds)
 
 

@@ -186,6 +186,58 @@ def test_photon_pass_matches_the_oracle(gpu_ctx):
     assert pair.gpu.photons_emit(lights, dirs[:, :0]).shape[0] == 0
 
 
+def test_photon_pass_with_the_cosines_and_sines_taken_on_the_device(gpu_ctx):
+    """Option photon_trig = 2: ZenithY::into_normal (src/geo/sphere.rs:29-34) evaluated by the GPU's own sin / cos.
+    The last place of those differs between libraries, so the photons are compared with the host-libm pass (which
+    equals the oracle bit for bit) within a tolerance: same paths, positions within 1e-9 of the scene's size -- far
+    inside the 1e-4 relative the hit times are allowed.  Directions in device memory give the same bytes as
+    directions from the host; host mode still refuses them."""
+    import torch
+    for build in ("default", "meshes"):
+        if build == "default":
+            objs, lights, _ = scenes.default_objects(0)
+            lights = _lights(lights)
+            pair = scenes.Pair(gpu_ctx, objs, {})
+        else:
+            pair, lights = _glass_mesh_scene(gpu_ctx)
+        dirs = np.stack([rtg.fibonacci_zenith_y(300_000, seed=l + 11) for l in range(lights.shape[0])])
+        want = pair.gpu.photons_emit(lights, dirs)
+        gpu_ctx.set_option("photon_trig", 2)
+        got = pair.gpu.photons_emit(lights, dirs)
+        room = got.shape[0] + 8
+        out = torch.zeros(room * rtg.PHOTON_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+        d_dirs = torch.from_numpy(dirs).cuda()
+        made = pair.gpu.photons_emit_raw(lights, (d_dirs.data_ptr(), dirs.shape[1]), out.data_ptr(), room)
+        gpu_ctx.synchronize()
+        gpu_ctx.set_option("photon_trig", 1)
+        assert want.shape[0] > 1000 and got.shape[0] == want.shape[0] == made
+        assert np.frombuffer(out.cpu().numpy().tobytes(), dtype=rtg.PHOTON_DTYPE)[:made].tobytes() == got.tobytes()
+        for name in ("n_bounces", "modes", "light_index", "surface_object", "surface_leaf"):
+            assert np.array_equal(got[name], want[name]), name
+        assert np.array_equal(got["dir"], want["dir"]) and np.array_equal(got["origin"], want["origin"])
+        assert np.abs(got["position"] - want["position"]).max() < 1e-9
+        assert np.allclose(got["light"], want["light"], rtol=1e-9, atol=0.0)
+        assert (got["position"] != want["position"]).any()          # it is another sin / cos
+        with pytest.raises(rtg.RtgError, match="host memory"):
+            pair.gpu.photons_emit_raw(lights, (d_dirs.data_ptr(), dirs.shape[1]), out.data_ptr(), room)
+        # directions made on the device from the seeds the host generator was given: the same map, photon for photon
+        seed = 0x1234
+        host_dirs = np.stack([rtg.fibonacci_zenith_y(300_000, seed=(seed + 0x9E3779B97F4A7C15 * l) % 2 ** 64)
+                              for l in range(lights.shape[0])])
+        gpu_ctx.set_option("photon_trig", 2)
+        a = pair.gpu.photon_map(lights, host_dirs)
+        gpu_ctx.set_option("photon_trig", 1)
+        b = pair.gpu.photon_map_fibonacci(lights, 300_000, seed)
+        assert a.n == b.n > 1000
+        q = got["position"][::5] + 1e-3
+        for k in (1, 3):
+            ia, da = a.nearest(q, k)
+            ib, db = b.nearest(q, k)
+            assert np.array_equal(ia, ib) and np.array_equal(da, db)
+        a.close()
+        b.close()
+
+
 def test_photons_stay_on_the_device(gpu_ctx):
     """The photon pass into device memory and a photon map made from that memory give what the host round trip
     gives: same records, same nearest photons."""
@@ -452,7 +504,7 @@ def test_renderer_with_its_photon_pass(gpu_ctx):
     """The host Renderer with the photon pass switched on (Renderer::render, src/render/renderer.rs:115-154) against
     the same steps taken one by one on the oracle: directions, photon pass, k-d tree, pixel pass."""
     time, w, h, count, seed = 7, 72, 72, 150_000, 5
-    got, n_photons, seconds = rtg.render_scene_builder_photons(gpu_ctx, time, w, h, count, seed=seed)
+    got, n_photons, seconds = rtg.render_scene_builder_photons(gpu_ctx, time, w, h, count, seed=seed, photons_on_host=True)
     objs, lights, view = scenes.default_objects(time)
     lights = _lights(lights)
     pair = scenes.Pair(gpu_ctx, objs, {})
@@ -468,6 +520,12 @@ def test_renderer_with_its_photon_pass(gpu_ctx):
     close = np.isclose(got[caustic], want[caustic], rtol=IRRAD_RTOL, atol=1e-300).all(axis=1)
     assert close.mean() > 0.99, close.mean()
     assert all(x >= 0.0 for x in seconds)
+    # the whole pass on the GPU (the Renderer's default): same directions, the GPU's sin / cos -- the same photons
+    # up to the last places, so the same picture within the caustic's tolerance
+    dev, n_dev, _ = rtg.render_scene_builder_photons(gpu_ctx, time, w, h, count, seed=seed)
+    assert n_dev == n_photons
+    assert not scenes.float_bits_differ(dev[~caustic], plain[~caustic]).any()
+    assert np.isclose(dev[caustic], want[caustic], rtol=IRRAD_RTOL, atol=1e-300).all(axis=1).mean() > 0.99
 
 
 def test_plain_c_caller_renders_the_default_frame(gpu_ctx, tmp_path):

@@ -4,7 +4,8 @@ checker floor at 300x300, two lights orbiting with `time`, 10 000 000 photon dir
 and 5 Newton steps per path point; every frame is written as the reference's three images.  Per frame: directions
 (the caller's side in the reference: Sphere::fibonacci_sphere), photon pass + k-d tree, pixel pass, image encoding.
 The CPU side is the oracle on a reduced photon count (its photon pass is linear in the count).
-Usage: tools/default_job.py [frames (default 5)] [photons per light (default 10000000)] [oracle photons per light (default 200000)]"""
+Usage: tools/default_job.py [frames (default 5)] [photons per light (default 10000000)] [oracle photons per light (default 200000)]
+       [host: photon directions and their sin / cos on the host instead of the GPU]"""
 import os
 import sys
 import time
@@ -22,11 +23,13 @@ oracle_count = int(sys.argv[3]) if len(sys.argv) > 3 else 200_000
 W = H = 300
 
 ctx = rtg.Context(0)
-rtg.render_scene_builder_photons(ctx, 0, W, H, min(count, 1_000_000))          # warm-up: scratch buffers, first launches
+ON_HOST = "host" in sys.argv[4:]              # directions and their sin / cos on the host (bit-exact with the oracle)
+rtg.render_scene_builder_photons(ctx, 0, W, H, min(count, 1_000_000), photons_on_host="host" in sys.argv[4:])          # warm-up: scratch buffers, first launches
 rows = []
 for frame in range(frames):
     t0 = time.perf_counter()
-    rgb, n_photons, (s_dirs, s_photons, s_pixels) = rtg.render_scene_builder_photons(ctx, frame, W, H, count, seed=frame + 1)
+    rgb, n_photons, (s_dirs, s_photons, s_pixels) = rtg.render_scene_builder_photons(ctx, frame, W, H, count, seed=frame + 1,
+                                                                                     photons_on_host=ON_HOST)
     t1 = time.perf_counter()
     tar = rtg.images_tar(rgb, W, H, seconds=s_pixels)
     t2 = time.perf_counter()
