@@ -336,7 +336,9 @@ int rtg_render_primary(rtg_scene *scene, const rtg_view *view, uint32_t width, u
  * always the default (persistent) traversal; the call neither allocates nor frees device or host memory and is
  * asynchronous on the context's stream.  The kernels' scratch (work counters, closest sphere/plane hit per pixel:
  * 32 MiB + 2 KiB) is a fixed array inside the library, one copy per GPU, shared by every call on that GPU: calls
- * that overlap on one GPU (two contexts or streams) race -- serialise them. */
+ * that overlap on one GPU (two contexts or streams) race -- serialise them.  (The HIP runtime itself sets a queue up
+ * on the first kernel launch of a stream, the kernels' private segment included; that happens once per stream,
+ * whichever entry point launches first, so a caller that must not see it warms the stream up with one small call.) */
 #define RTG_STATIC_MAX_PIXELS (1u << 21)
 int rtg_render_primary_static(rtg_scene *scene, const rtg_view *view, uint32_t width, uint32_t height,
                               rtg_rect tile, rtg_hit *out_hits);

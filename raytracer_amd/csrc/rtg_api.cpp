@@ -475,7 +475,7 @@ int rtg_ctx_create(int hip_device, rtg_ctx **out) try {
         delete ctx;
         return fail(nullptr, RTG_E_HIP, "stream create on device %d: %s", hip_device, hipGetErrorString(e));
     }
-    e = static_scratch_init(hip_device);     // this GPU's address of the fixed scratch (rtg_render_primary_static)
+    e = static_scratch_init(hip_device, &ctx->static_scratch);     // this GPU's address of the fixed scratch (rtg_render_primary_static)
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipStreamDestroy(ctx->own_stream);

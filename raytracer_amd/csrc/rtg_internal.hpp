@@ -33,6 +33,8 @@ struct rtg_ctx {
     // option "comm_loopback": a communicator created on this context is a real RCCL communicator even with one rank,
     // and the root's own pieces travel by ncclSend / ncclRecv to itself (the several-rank machinery on one GPU)
     bool comm_loopback = false;
+    // this GPU's copy of the fixed scratch array behind rtg_render_primary_static, looked up when the context is made
+    unsigned char *static_scratch = nullptr;
     // option "photon_trig": the photon directions' cosines and sines come from the device's own routines instead of
     // the host's libm (ZenithY::into_normal, src/geo/sphere.rs:29-34)
     bool photon_trig_device = false;

@@ -175,8 +175,8 @@ hipError_t launch_frame_from_paths(hipStream_t stream, const rtg_path *paths, ui
                                    uint64_t n_pixels, double *out_rgb, uint8_t *out_rgba8);
 
 // Looks up this GPU's copy of the fixed scratch array behind rtg_render_primary_static (rtg_static.hip); called
-// with `device` current, once per device (later calls return at once).
-hipError_t static_scratch_init(int device);
+// with `device` current, once per device (later calls return the address found then).  *out is the device address.
+hipError_t static_scratch_init(int device, unsigned char **out);
 
 hipError_t launch_selftest_div(hipStream_t stream, uint64_t seed, uint32_t blocks, uint32_t per_thread, uint32_t family,
                                uint64_t *out3);

@@ -33,10 +33,14 @@ unsigned char *g_scratch_of_device[kMaxDevices];   // zero-initialised: not look
 
 namespace rtg {
 
-hipError_t static_scratch_init(int device) {
+hipError_t static_scratch_init(int device, unsigned char **out) {
+    *out = nullptr;
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> guard(g_lock);
-    if (g_scratch_of_device[device]) return hipSuccess;
+    if (g_scratch_of_device[device]) {
+        *out = g_scratch_of_device[device];
+        return hipSuccess;
+    }
     int current = -1;
     hipError_t e = hipGetDevice(&current);
     if (e != hipSuccess) return e;
@@ -46,6 +50,7 @@ hipError_t static_scratch_init(int device) {
     if (e != hipSuccess) return e;
     if (!ptr) return hipErrorInvalidSymbol;
     g_scratch_of_device[device] = ptr;
+    *out = ptr;
     return hipSuccess;
 }
 
@@ -75,9 +80,19 @@ extern "C" int rtg_render_primary_static(rtg_scene *scene, const rtg_view *view,
         return api_fail(ctx, RTG_E_INVALID,
                         "rtg_render_primary_static: out_hits must be device memory (a host buffer would need a staging "
                         "allocation)");
+    {
+        hipPointerAttribute_t attr{};          // a query, not an allocation
+        if (hipPointerGetAttributes(&attr, out_hits) != hipSuccess) {
+            (void)hipGetLastError();
+            return api_fail(ctx, RTG_E_INVALID, "rtg_render_primary_static: out_hits is not a known device address");
+        }
+        if (attr.device != ctx->device)
+            return api_fail(ctx, RTG_E_INVALID, "rtg_render_primary_static: out_hits lives on GPU %d, the scene on GPU %d",
+                            attr.device, ctx->device);
+    }
     if ((uintptr_t)out_hits % 16 != 0)
         return api_fail(ctx, RTG_E_INVALID, "rtg_render_primary_static: out_hits must be 16-byte aligned");
-    unsigned char *base = (ctx->device >= 0 && ctx->device < kMaxDevices) ? g_scratch_of_device[ctx->device] : nullptr;
+    unsigned char *base = ctx->static_scratch;      // looked up under the lock when the context was made
     if (!base) return api_fail(ctx, RTG_E_HIP, "rtg_render_primary_static: no static scratch on device %d", ctx->device);
 
     DevScene ds = scene->dev;           // always the persistent kernel: the per-lane traversals may need a stack slab

@@ -53,6 +53,36 @@ def test_static_entry_point_equals_render_primary_twice_in_a_row(gpu_ctx):
         assert scenes.hit_mismatches(got, want).size == 0
 
 
+def test_static_entry_point_leaves_device_memory_as_it_is(gpu_ctx):
+    """What the entry point is for: calls on a context that has never rendered through the allocating entry points
+    (no scratch buffer of its own yet) leave the GPU's free memory exactly where it was, for frames of several sizes,
+    while the same frame through rtg_render_primary makes that context allocate its scratch."""
+    import torch
+    fresh = rtg.Context(0)
+    tris, xform = scenes.terrain(40, 40, seed=5)
+    objs, _, view = scenes.mesh_scene_objects(xform)
+    mesh = fresh.mesh(rtg.HostBvh(tris))
+    objs[2].mesh = mesh.handle
+    scene = fresh.scene(objs)
+    out = torch.empty(1024 * 768 * 16, dtype=torch.uint8, device="cuda")
+    # the first launch on a new stream lets the HIP runtime set up that queue (the kernel's private segment among
+    # other things: 40 MiB on this GPU) -- the runtime's doing, once per queue, and no call of the library's
+    scene.render_primary_static(view, 64, 64, (0, 0, 64, 64), out.data_ptr())
+    fresh.synchronize()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for w, h in ((1024, 768), (333, 111), (1024, 768)):
+        scene.render_primary_static(view, w, h, (0, 0, w, h), out.data_ptr())
+    fresh.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
+    scene.render_primary_raw(view, 1024, 768, (0, 0, 1024, 768), out.data_ptr())      # the allocating path, for contrast
+    fresh.synchronize()
+    assert torch.cuda.mem_get_info()[0] < free_before
+    scene.close()
+    mesh.close()
+    fresh.close()
+
+
 def test_static_entry_point_limits(gpu_ctx):
     import torch
     scene, view, mesh = _scene(gpu_ctx)
