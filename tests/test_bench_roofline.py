@@ -14,19 +14,23 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import bench  # noqa: E402
 import roofline_ceiling  # noqa: E402
 
-CASES = [("config2-1920x1080", 1920 * 1080, 0.0, 2097152, lambda rec: rec["roofline"]),
-         ("config4-64Mrays-10Mtris", 1 << 26, 48.0, 33554432, lambda rec: rec["configs"]["c4"]["roofline"])]
+CASES = [("config2-1920x1080", 1920 * 1080, 0.0, 2097152, 72.0, lambda rec: rec["roofline"]),
+         ("config4-64Mrays-10Mtris", 1 << 26, 48.0, 33554432, 72.0, lambda rec: rec["configs"]["c4"]["roofline"]),
+         ("config3-3840x2160-patches", 3840 * 2160, 0.0, 2097152, 312.0, lambda rec: rec["configs"]["c3"]["roofline"])]
+
+
+def _newest():
+    return sorted(d for d in os.listdir(os.path.join(ROOT, "profiles"))
+                  if os.path.isfile(os.path.join(ROOT, "profiles", d, "bench.json")))[-1]
 
 
 def _record():
-    newest = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles"))
-                    if os.path.isfile(os.path.join(ROOT, "profiles", d, "bench.json")))[-1]
-    with open(os.path.join(ROOT, "profiles", newest, "bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", _newest(), "bench.json")) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("workload,n_rays,ray_bytes,beyond,pick", CASES)
-def test_ceiling_follows_from_the_microbenchmark_and_the_counters(workload, n_rays, ray_bytes, beyond, pick):
+@pytest.mark.parametrize("workload,n_rays,ray_bytes,beyond,leaf_bytes,pick", CASES)
+def test_ceiling_follows_from_the_microbenchmark_and_the_counters(workload, n_rays, ray_bytes, beyond, leaf_bytes, pick):
     c = bench.committed("ceiling.json", workload, "k_trace_phased")
     assert c is not None
     r1, r2, r3 = roofline_ceiling.gather_rates(os.path.join(ROOT, c["gather_lane_loads_per_s"]["source"]), beyond)
@@ -43,15 +47,23 @@ def test_ceiling_follows_from_the_microbenchmark_and_the_counters(workload, n_ra
     assert c["ceiling_visits_per_s"] == pytest.approx(lane_loads / c["loads_per_visit"], rel=1e-4)
 
 
-@pytest.mark.parametrize("workload,n_rays,ray_bytes,beyond,pick", CASES)
-def test_committed_bench_record_follows_from_the_committed_evidence(workload, n_rays, ray_bytes, beyond, pick):
+@pytest.mark.parametrize("workload,n_rays,ray_bytes,beyond,leaf_bytes,pick", CASES)
+def test_committed_bench_record_follows_from_the_committed_evidence(workload, n_rays, ray_bytes, beyond, leaf_bytes, pick):
     roof = pick(_record())
     again = bench.roofline_record("k_trace_phased", workload, roof["kernel_ms"], n_rays, roof["nodes_per_ray"],
-                                  roof["tris_per_ray"], ray_bytes, True)
-    for part in ("gather", "hbm"):
+                                  roof["tris_per_ray"], ray_bytes, True, leaf_bytes=leaf_bytes)
+    for part in ("gather", "hbm", "little"):
         assert 0 < roof[part]["frac"] <= 1
         assert again[part]["frac"] == pytest.approx(roof[part]["frac"], rel=2e-3)
         assert again[part]["peak"] == pytest.approx(roof[part]["peak"], rel=1e-6)
+    assert again["algorithmic"]["bytes_per_ray"] == pytest.approx(roof["algorithmic"]["bytes_per_ray"], rel=2e-3)
+    # the latency ceiling: resident rays over the measured latency of a vector-memory instruction
+    lat = bench.committed("latency.json", workload, "k_trace_phased")
+    assert roof["little"]["peak"] == pytest.approx(
+        1024 * lat["waves_per_simd"] * 64 / (lat["vmem_latency_cycles"] / (lat["clock_ghz"] * 1e9)) / 1e9, rel=1e-3)
+    assert lat["vmem_latency_cycles"] == pytest.approx(
+        lat["counters"]["SQ_INST_LEVEL_VMEM"] / lat["counters"]["SQ_INSTS_VMEM"] if "VmemLatency" not in lat["counters"]
+        else lat["counters"]["VmemLatency"], rel=1e-3)
     assert roof["frac"] == max(roof["gather"]["frac"], roof["hbm"]["frac"]) and roof["frac"] <= 1
     assert again["bound"] == roof["bound"]
     # traffic: the counter bytes of the committed pass, corrected as the file says
@@ -66,13 +78,13 @@ def test_launch_duration_agrees_with_the_rocprofv3_summary_of_the_same_command()
     bench_under_rocprof.json is the line that very run printed.  The duration bench.py takes from the launches' own
     events and the profiler's average over the same launches (warm-up included) agree within 2 %."""
     import csv
-    d = os.path.join(ROOT, "profiles", "r2_3_final")
+    d = os.path.join(ROOT, "profiles", _newest())
     with open(os.path.join(d, "bench_under_rocprof.json")) as f:
         rec = json.loads(f.read().strip().splitlines()[-1])
     rows = [r for r in csv.DictReader(open(os.path.join(d, "kernel_stats.csv")))
             if "k_trace_phased<rtg::PrimarySource, false" in r["Name"]]
     assert len(rows) == 1
-    assert int(rows[0]["Calls"]) == rec["warmup"] + rec["steps"] * rec["windows"]
+    assert int(rows[0]["Calls"]) == rec["warmup"] + rec["settle_steps"] + rec["steps"] * rec["windows"]
     assert float(rows[0]["AverageNs"]) / 1e6 == pytest.approx(rec["roofline"]["kernel_ms"], rel=0.02)
     # the dominant kernel: nearly all of the GPU time of the run
     assert float(rows[0]["Percentage"]) > 95
