@@ -318,10 +318,12 @@ int layout_tree(rtg_ctx *ctx, const rtg_bvh *bvh, std::vector<DevNode> &ref_node
 
 // Takes the threaded nodes in pre-order (link = pre-order index of the node after the subtree) and gives every node
 // its position, its skip link and its pass link (DevNode::nchild) by position.  A tree in which no node has leaves
-// and children at once -- every tree the builders make -- is stored with the children of a node side by side, the
-// groups in depth-first order of their parents and the root last, so that pairs of siblings start at even positions
-// and share a 64-byte half line; any other tree stays in pre-order (a node with leaves goes on to its children only
-// after its leaves, which the kernels read from the full node).  The visit order is the same in every placement.
+// and children at once -- every tree the builders make -- is stored with the children of a node side by side and the
+// root last, so that pairs of siblings start at even positions and share a 64-byte half line.  The groups of the
+// parents in the top kThreadedTopLevels levels come first, level by level (what every ray touches sits in one
+// compact block), then the groups of all deeper parents in depth-first order.  Any other tree stays in pre-order (a
+// node with leaves goes on to its children only after its leaves, which the kernels read from the full node).  The
+// visit order is the same in every placement.
 void place_threaded(std::vector<DevNode> &thr_nodes, uint32_t &troot_out) {
     const uint32_t n = (uint32_t)thr_nodes.size();
     troot_out = 0;
@@ -332,15 +334,27 @@ void place_threaded(std::vector<DevNode> &thr_nodes, uint32_t &troot_out) {
         for (uint32_t i = 0; i < n; i++) thr_nodes[i].nchild = i + 1 < thr_nodes[i].link ? i + 1 : thr_nodes[i].link;
         return;
     }
-    std::vector<uint32_t> order, stack, kids;
+    std::vector<uint32_t> order, stack, kids, level, below;
     order.reserve(n);
-    stack.push_back(0);
-    while (!stack.empty()) {
-        const uint32_t i = stack.back();
-        stack.pop_back();
+    auto place_children_of = [&](uint32_t i) {
         kids.clear();
         for (uint32_t c = i + 1; c < thr_nodes[i].link; c = thr_nodes[c].link) kids.push_back(c);
         for (uint32_t c : kids) order.push_back(c);
+    };
+    level.push_back(0);
+    for (uint32_t d = 0; d < kThreadedTopLevels && !level.empty(); d++) {      // the top levels, breadth first
+        below.clear();
+        for (uint32_t i : level) {
+            place_children_of(i);
+            for (uint32_t c : kids) below.push_back(c);
+        }
+        level.swap(below);
+    }
+    for (size_t k = level.size(); k-- > 0;) stack.push_back(level[k]);         // what hangs below them, depth first
+    while (!stack.empty()) {
+        const uint32_t i = stack.back();
+        stack.pop_back();
+        place_children_of(i);
         for (size_t k = kids.size(); k-- > 0;) stack.push_back(kids[k]);
     }
     order.push_back(0);

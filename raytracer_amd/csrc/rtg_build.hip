@@ -20,10 +20,13 @@
 //
 // Build nodes live in pre-order slots (a subtree over k triangles owns 2k-1 consecutive slots); the position of a
 // node's entry in the reference's flattened order (children after all descendants, root last) and its position in
-// the threaded arrays the traversal kernels read (siblings side by side, pairs in pre-order of their parents, root
-// last) follow from the same counts: the inner node at slot s whose triangles start at b is the (s - b)-th inner
-// node in pre-order, so its children sit at 2 (s - b) and 2 (s - b) + 1.  The last two kernels write the mesh slab,
-// the reference-order node array and the leaf -> source-triangle map.
+// the threaded arrays the traversal kernels read (siblings side by side, root last; first the pairs under the T
+// inner nodes of the top kThreadedTopLevels levels, level by level, then the pairs under all deeper inner nodes in
+// pre-order) follow from the same counts: the inner node at slot s whose triangles start at b is the (s - b)-th
+// inner node in pre-order, so a deep one is pair T + (s - b) - (top inner nodes before s), and a top one is pair
+// (top inner nodes of lower depth, or of the same depth and before s).  The children of pair g sit at 2 g and
+// 2 g + 1.  The last two kernels write the mesh slab, the reference-order node array and the leaf ->
+// source-triangle map.
 #include <hip/hip_runtime.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -43,8 +46,9 @@ struct BuildNode {
     uint32_t base;           // entries of the flattened array emitted before this subtree's descendants
     uint32_t ref;            // index of this node's entry in the flattened array
     uint32_t split;          // triangles in the left child (0 while unsplit / for a leaf)
-    uint32_t axis;           // bits 0..1 sort axis, bit 31 = last of its siblings
-    uint32_t pos;            // position in the threaded arrays
+    uint32_t axis;           // bits 0..1 sort axis, bits 8..15 depth + 1 of an inner node of the top levels (else 0),
+                             // bit 31 = last of its siblings
+    uint32_t pos;            // position in the threaded arrays (set by k_place_*)
 };
 
 constexpr uint64_t kSign = 0x8000000000000000ull;
@@ -249,7 +253,7 @@ __global__ void k_plan(BuildNode *__restrict__ nodes, const uint64_t *__restrict
     for (int k = 1; k < 3; k++)
         if (dim[k] >= dim[axis]) axis = k;
     split_coord[a] = lo[axis] + dim[axis] / 2.0;
-    nodes[x].axis = (nodes[x].axis & 0x80000000u) | (uint32_t)axis;
+    nodes[x].axis = (nodes[x].axis & 0x8000FF00u) | (uint32_t)axis;
 }
 
 __global__ void k_keys(const BuildNode *__restrict__ nodes, const uint32_t *__restrict__ seg,
@@ -266,11 +270,12 @@ __global__ void k_keys(const BuildNode *__restrict__ nodes, const uint32_t *__re
 __global__ void k_split(BuildNode *__restrict__ nodes, uint64_t *__restrict__ bounds,
                         const uint32_t *__restrict__ active, uint32_t n_active, const double *__restrict__ split_coord,
                         const uint32_t *__restrict__ ids, const double *__restrict__ centre, uint32_t n,
-                        uint32_t *__restrict__ next_active, uint32_t *__restrict__ next_count) {
+                        uint32_t *__restrict__ next_active, uint32_t *__restrict__ next_count, uint32_t level) {
     uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_active) return;
     const uint32_t x = active[a];
     BuildNode nd = nodes[x];
+    if (level < kThreadedTopLevels) nodes[x].axis = nd.axis | ((level + 1u) << 8);
     const uint32_t b = nd.begin, k = nd.count;
     const double *key = centre + (size_t)(nd.axis & 3u) * n;
     const double want = split_coord[a];
@@ -296,8 +301,8 @@ __global__ void k_split(BuildNode *__restrict__ nodes, uint64_t *__restrict__ bo
     if (split > max_split) split = max_split;
     nodes[x].split = split;
     const uint32_t l = x + 1, r = x + 2 * split;
-    nodes[l] = BuildNode{b, split, nd.base, nd.base + 2 * k - 4, 0u, 0u, 2 * (x - b)};
-    nodes[r] = BuildNode{b + split, k - split, nd.base + 2 * split - 2, nd.base + 2 * k - 3, 0u, 0x80000000u, 2 * (x - b) + 1};
+    nodes[l] = BuildNode{b, split, nd.base, nd.base + 2 * k - 4, 0u, 0u, 0u};
+    nodes[r] = BuildNode{b + split, k - split, nd.base + 2 * split - 2, nd.base + 2 * k - 3, 0u, 0x80000000u, 0u};
     for (int c = 0; c < 3; c++) {
         bounds[(size_t)l * 6 + c] = ord_of(kInf);
         bounds[(size_t)l * 6 + 3 + c] = ord_of(-kInf);
@@ -306,6 +311,40 @@ __global__ void k_split(BuildNode *__restrict__ nodes, uint64_t *__restrict__ bo
     }
     if (split >= 2) next_active[atomicAdd(next_count, 1u)] = l;
     if (k - split >= 2) next_active[atomicAdd(next_count, 1u)] = r;
+}
+
+// Positions in the threaded arrays.  k_top_flag marks the inner nodes of the top levels; after an exclusive scan of
+// the marks (`before`), k_top_list packs their (depth, slot) keys in slot order, k_place_top ranks every key among
+// all of them (a few thousand at most) and k_place_deep counts pre-order ranks; both write the two children's
+// positions.
+__global__ void k_top_flag(const BuildNode *__restrict__ nodes, uint32_t n_nodes, uint32_t *__restrict__ flag) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_nodes) flag[s] = (nodes[s].axis & 0xFF00u) ? 1u : 0u;
+}
+__global__ void k_top_list(const BuildNode *__restrict__ nodes, uint32_t n_nodes, const uint32_t *__restrict__ flag,
+                           const uint32_t *__restrict__ before, uint64_t *__restrict__ list) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_nodes && flag[s]) list[before[s]] = ((uint64_t)((nodes[s].axis >> 8) & 0xFFu) << 32) | s;
+}
+__global__ void k_place_top(BuildNode *__restrict__ nodes, const uint64_t *__restrict__ list, uint32_t n_top) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_top) return;
+    const uint64_t key = list[j];
+    uint32_t g = 0;
+    for (uint32_t i = 0; i < n_top; i++) g += list[i] < key ? 1u : 0u;
+    const uint32_t s = (uint32_t)key;
+    nodes[s + 1].pos = 2 * g;
+    nodes[s + 2 * nodes[s].split].pos = 2 * g + 1;
+}
+__global__ void k_place_deep(BuildNode *__restrict__ nodes, uint32_t n_nodes, const uint32_t *__restrict__ flag,
+                             const uint32_t *__restrict__ before, uint32_t n_top) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_nodes || flag[s]) return;
+    const BuildNode nd = nodes[s];
+    if (nd.count < 2) return;
+    const uint32_t g = n_top + (s - nd.begin) - before[s];
+    nodes[s + 1].pos = 2 * g;
+    nodes[s + 2 * nd.split].pos = 2 * g + 1;
 }
 
 // Node outputs: the threaded node and its single-precision companion at the node's threaded position (skip link =
@@ -329,7 +368,7 @@ __global__ void k_emit_nodes(const BuildNode *__restrict__ nodes, const uint64_t
         const uint32_t k = nd.count;
         const uint32_t after = s + 2 * k - 1;
         t.link = after < n_nodes ? nodes[after].pos : n_nodes;
-        t.nchild = k == 1 ? t.link : 2 * (s - nd.begin);
+        t.nchild = k == 1 ? t.link : nodes[s + 1].pos;
         t.leaf_begin = nd.begin;
         t.leaf_count = k == 1 ? 1u : 0u;
         thr[nd.pos] = t;
@@ -470,12 +509,16 @@ hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uin
     RTG_TRY(buf.get(64, (void **)&small));       // [0] vertex flags, [1] next-active count, [2] range summary, [4..5] max |c|
     RTG_TRY(hipMemsetAsync(small, 0, 64, stream));
 
-    size_t temp_rank = 0, temp_level = 0, temp_scan = 0;
+    size_t temp_rank = 0, temp_level = 0, temp_scan = 0, temp_place = 0;
     RTG_TRY(rocprim::radix_sort_pairs(nullptr, temp_rank, sort_key, sorted_key, iota, perm, (size_t)n, 0u, 64u, stream));
     RTG_TRY(rocprim::radix_sort_pairs(nullptr, temp_level, keys_a, keys_b, ids_a, ids_b, (size_t)n, 0u, 2 * bits, stream));
     RTG_TRY(rocprim::inclusive_scan(nullptr, temp_scan, heads, run_start, (size_t)n, rocprim::maximum<uint32_t>(), stream));
+    // the placement pass reuses the level sort's key arrays (2n words each) for its marks and their scan
+    RTG_TRY(rocprim::exclusive_scan(nullptr, temp_place, (uint32_t *)keys_a, (uint32_t *)keys_b, 0u, (size_t)n_nodes,
+                                    rocprim::plus<uint32_t>(), stream));
     size_t temp_bytes = temp_rank > temp_level ? temp_rank : temp_level;
     if (temp_scan > temp_bytes) temp_bytes = temp_scan;
+    if (temp_place > temp_bytes) temp_bytes = temp_place;
     void *temp;
     RTG_TRY(buf.get(temp_bytes, &temp));
 
@@ -510,7 +553,7 @@ hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uin
                        (unsigned long long *)bounds);
     RTG_TRY(hipGetLastError());
     RTG_TRY(hipMemsetAsync(active_a, 0, 4, stream));     // the root is the only active segment
-    uint32_t n_active = 1, depth = 1;
+    uint32_t n_active = 1, depth = 1, n_top = 0;
     uint32_t *ids_cur = ids_a, *ids_next = ids_b;
     while (n_active) {
         const uint32_t ga = grid_for(n_active);
@@ -522,7 +565,8 @@ hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uin
         RTG_TRY(rocprim::radix_sort_pairs(temp, tbytes, keys_a, keys_b, ids_cur, ids_next, (size_t)n, 0u, 2 * bits, stream));
         RTG_TRY(hipMemsetAsync(small + 1, 0, 4, stream));
         hipLaunchKernelGGL(k_split, dim3(ga), dim3(256), 0, stream, nodes, bounds, active_a, n_active, split_coord,
-                           ids_next, centre, n, active_b, small + 1);
+                           ids_next, centre, n, active_b, small + 1, depth - 1);
+        if (depth - 1 < kThreadedTopLevels) n_top += n_active;
         RTG_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_assign, dim3(g_assign), dim3(256), 0, stream, nodes, seg, ids_next, tb, n, 0,
                            (unsigned long long *)bounds);
@@ -536,6 +580,28 @@ hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uin
         std::swap(ids_cur, ids_next);
         std::swap(active_a, active_b);
         depth++;
+    }
+
+    // positions in the threaded arrays
+    {
+        uint32_t *flag = (uint32_t *)keys_a, *before = (uint32_t *)keys_b;
+        uint64_t *list;
+        RTG_TRY(buf.get(sizeof(uint64_t) << kThreadedTopLevels, (void **)&list));
+        if (n_top == 0 || n_top >= (1u << kThreadedTopLevels)) {
+            err = "build_subdivide_device: top-level node count out of range";
+            return hipErrorUnknown;
+        }
+        const uint32_t gn = grid_for(n_nodes);
+        hipLaunchKernelGGL(k_top_flag, dim3(gn), dim3(256), 0, stream, nodes, n_nodes, flag);
+        RTG_TRY(hipGetLastError());
+        size_t tbytes = temp_bytes;
+        RTG_TRY(rocprim::exclusive_scan(temp, tbytes, flag, before, 0u, (size_t)n_nodes, rocprim::plus<uint32_t>(), stream));
+        hipLaunchKernelGGL(k_top_list, dim3(gn), dim3(256), 0, stream, nodes, n_nodes, flag, before, list);
+        RTG_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_place_top, dim3(grid_for(n_top)), dim3(256), 0, stream, nodes, list, n_top);
+        RTG_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_place_deep, dim3(gn), dim3(256), 0, stream, nodes, n_nodes, flag, before, n_top);
+        RTG_TRY(hipGetLastError());
     }
 
     // outputs

@@ -43,10 +43,14 @@ static_assert(sizeof(DevTri) == 80, "triangle must be 5 x 16 B");
 // order: `skip` is where a walk goes on when the box test fails (the node after
 // the subtree in the reference's visit order, or n_nodes at the end), the pass
 // link where it goes on when it passes.  The host and device builders place the
-// children of a node side by side and the pairs in depth-first order of their
-// parents, root last (DevMesh::troot): a visit of a passed node's second child
-// then finds it in the 64-byte half line the first child came with.  Trees in
-// which a node has leaves and children at once keep the pre-order array.
+// children of a node side by side and the root last (DevMesh::troot): a visit of
+// a passed node's second child then finds it in the 64-byte half line the first
+// child came with.  The pairs under the parents of the top kThreadedTopLevels
+// levels come first, level by level and in pre-order within a level -- the part
+// of the tree every ray walks is one compact block --, the pairs of all deeper
+// parents follow in pre-order of the parents.  Trees in which a node has leaves
+// and children at once keep the pre-order array.
+constexpr uint32_t kThreadedTopLevels = 12;
 //
 // 32-byte companion of a threaded node for the single-precision pre-test: the
 // box rounded to f32 with the two planes of an axis side by side (lo.x, hi.x,
