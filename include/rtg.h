@@ -254,6 +254,8 @@ int rtg_ctx_synchronize(rtg_ctx *ctx);
  *                     and nothing but 16 bytes per direction crosses PCIe; photon positions agree with host mode to
  *                     about 1e-15 relative, not bit for bit (the last place of sin / cos differs between libraries,
  *                     as it does between the platforms the reference runs on); 1 = host libm (default)
+ *   "photon_batch" 12..24 = log2 of the photon directions handled per batch (default 23): a batch holds 140 bytes per
+ *                     direction in scratch memory and costs a fixed number of launches and waits for the host
  *   "time_kernels" 2 = record each persistent-kernel launch's execution window (rtg_ctx_kernel_time), 1 = off */
 int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value);
 /* With option "time_kernels" = 2 every persistent-kernel launch behind rtg_render_primary / rtg_trace records its

@@ -595,6 +595,11 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) try {
         ctx->photon_trig_device = value > 1;     // 2 = device, 1 = host libm
         return RTG_OK;
     }
+    if (std::strcmp(key, "photon_batch") == 0) {
+        if (value < 12 || value > 24) return fail(ctx, RTG_E_INVALID, "photon_batch must be 12..24 (log2 of the directions per batch)");
+        ctx->photon_batch_log2 = (uint32_t)value;
+        return RTG_OK;
+    }
     if (std::strcmp(key, "comm_loopback") == 0) {
         ctx->comm_loopback = value > 1;          // 2 = on, 1 = off
         return RTG_OK;

@@ -38,6 +38,10 @@ struct rtg_ctx {
     // option "photon_trig": the photon directions' cosines and sines come from the device's own routines instead of
     // the host's libm (ZenithY::into_normal, src/geo/sphere.rs:29-34)
     bool photon_trig_device = false;
+    // option "photon_batch": log2 of the photon directions handled per batch.  A batch keeps 140 bytes per direction in
+    // scratch memory (rays, first hits, the packed rays that can make photons) and costs a fixed number of launches
+    // and a few waits for the host; the path records are made for at most 2^20 of the packed rays at a time.
+    uint32_t photon_batch_log2 = 23;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, idle_events;
     // rtg_render_frame renders a frame of an opaque scene as two row bands on two streams (option "frame_bands"):
     // `side` is an internal context (own stream and scratch) for the second band, joined back by events

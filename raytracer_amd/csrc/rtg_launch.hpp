@@ -142,12 +142,20 @@ hipError_t launch_photon_rays_trig(hipStream_t stream, const double *dirs2_in, u
                                    uint64_t first_ray, uint64_t count_per_light, double *rays6, double *dirs2);
 hipError_t launch_photon_rays_fibonacci(hipStream_t stream, uint32_t n, const rtg_light *lights, uint64_t first_ray,
                                         uint64_t count_per_light, uint64_t seed, double *rays6, double *dirs2);
+// The rays of a batch that can make photons (their first hit lies on an object with a refracting material), packed
+// in their order: flags + exclusive scan (offsets[i] = kept rays before ray i; the count is offsets[n-1] + flags[n-1])
+// + copy; kept_index[j] = batch index of kept ray j.
+hipError_t launch_photon_first_filter(hipStream_t stream, const DevScene &scene, const rtg_hit *hits, const double *rays6,
+                                      uint32_t n, uint32_t *flags, uint32_t *offsets, void *temp, size_t temp_bytes,
+                                      double *kept_rays6, uint32_t *kept_index);
 // Photons of one batch of path records: flags + exclusive scan (offsets[i] = photons before path i) + records
-// written at out[offsets[i]] while that is below `room`.
+// written at out[offsets[i]] while that is below `room`.  Path ray r is ray ray_index[r] of the batch `dirs2` and
+// `first_ray` describe.
 size_t photon_scan_temp_bytes(uint32_t n);
 hipError_t launch_photons_from_paths(hipStream_t stream, const rtg_path *paths, uint32_t n_paths, const double *dirs2,
-                                     const rtg_light *lights, uint64_t first_ray, uint64_t count_per_light, uint32_t *flags,
-                                     uint32_t *offsets, void *temp, size_t temp_bytes, uint64_t room, rtg_photon *out);
+                                     const uint32_t *ray_index, const rtg_light *lights, uint64_t first_ray,
+                                     uint64_t count_per_light, uint32_t *flags, uint32_t *offsets, void *temp,
+                                     size_t temp_bytes, uint64_t room, rtg_photon *out);
 // The (surface point, photon sample) pairs the caustic correction works on; pair e = point * samples + sample.
 struct PhotonPairs {
     const DevObject *objects = nullptr;

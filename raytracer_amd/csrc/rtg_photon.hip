@@ -510,13 +510,44 @@ __global__ __launch_bounds__(256) void k_photon_rays_fibonacci(uint32_t n, const
     w[2] = make_double2(y, sn * radius);
     reinterpret_cast<double2 *>(dirs2)[i] = make_double2(zenith, y);
 }
+// Only a ray whose first hit lies on a refracting material has a path tree, and only paths below the root make
+// photons (renderer.rs:124-127): the pass traces every direction's first hit, keeps the rays whose hit object has such
+// a material (the object's two materials are not told apart here: keeping too many only costs time) in their order,
+// and builds path records for those alone.  kept_index[j] is the batch index of kept ray j.
+__global__ __launch_bounds__(256) void k_photon_first_flags(DevScene s, const rtg_hit *__restrict__ hits, uint32_t n,
+                                                            uint32_t *__restrict__ flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t object = hits[i].object;
+    bool keep = false;
+    if (object < s.n_objects) {
+        const DevObject &o = s.objects[object];
+        keep = o.material.has_dielectric != 0 || o.material2.has_dielectric != 0;
+    }
+    flags[i] = keep ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_photon_keep(const double *__restrict__ rays6, const uint32_t *__restrict__ flags,
+                                                     const uint32_t *__restrict__ offsets, uint32_t n,
+                                                     double *__restrict__ kept_rays6, uint32_t *__restrict__ kept_index) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const uint32_t j = offsets[i];
+    const double2 *src = reinterpret_cast<const double2 *>(rays6) + (size_t)i * 3;
+    double2 *dst = reinterpret_cast<double2 *>(kept_rays6) + (size_t)j * 3;
+    dst[0] = src[0];
+    dst[1] = src[1];
+    dst[2] = src[2];
+    kept_index[j] = i;
+}
 __global__ __launch_bounds__(256) void k_photon_flags(const rtg_path *__restrict__ paths, uint32_t n, uint32_t *__restrict__ flags) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flags[i] = paths[i].depth >= 1 ? 1u : 0u;      // `if path.modes.len() == 0 { return None }`
 }
-// render/renderer.rs:129-136; `first_ray` is the batch's first ray among all the rays of the pass
+// render/renderer.rs:129-136; `first_ray` is the batch's first ray among all the rays of the pass, path ray r is ray
+// ray_index[r] of the batch (`dirs2` holds the batch's directions)
 __global__ __launch_bounds__(256) void k_photon_write(const rtg_path *__restrict__ paths, uint32_t n,
                                                       const uint32_t *__restrict__ offsets, const double *__restrict__ dirs2,
+                                                      const uint32_t *__restrict__ ray_index,
                                                       const rtg_light *__restrict__ lights, uint64_t first_ray,
                                                       uint64_t count_per_light, uint64_t room, rtg_photon *__restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -525,7 +556,8 @@ __global__ __launch_bounds__(256) void k_photon_write(const rtg_path *__restrict
     if (p.depth < 1) return;
     const uint64_t slot = offsets[i];
     if (slot >= room) return;
-    const uint64_t ray = first_ray + p.ray;
+    const uint32_t in_batch = ray_index[p.ray];
+    const uint64_t ray = first_ray + in_batch;
     const uint32_t l = (uint32_t)(ray / count_per_light);
     rtg_photon ph;
     for (int k = 0; k < 3; k++) {
@@ -535,8 +567,8 @@ __global__ __launch_bounds__(256) void k_photon_write(const rtg_path *__restrict
         ph.surface_object[k] = RTG_NONE;
         ph.surface_leaf[k] = RTG_NONE;
     }
-    ph.dir[0] = dirs2[(size_t)p.ray * 2];
-    ph.dir[1] = dirs2[(size_t)p.ray * 2 + 1];
+    ph.dir[0] = dirs2[(size_t)in_batch * 2];
+    ph.dir[1] = dirs2[(size_t)in_batch * 2 + 1];
     ph.n_bounces = p.depth;
     ph.modes = p.modes;
     ph.light_index = l;
@@ -851,16 +883,29 @@ size_t photon_scan_temp_bytes(uint32_t n) {
     return bytes;
 }
 
+hipError_t launch_photon_first_filter(hipStream_t stream, const DevScene &scene, const rtg_hit *hits, const double *rays6,
+                                      uint32_t n, uint32_t *flags, uint32_t *offsets, void *temp, size_t temp_bytes,
+                                      double *kept_rays6, uint32_t *kept_index) {
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_photon_first_flags, dim3(blocks), dim3(256), 0, stream, scene, hits, n, flags);
+    hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, flags, offsets, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_photon_keep, dim3(blocks), dim3(256), 0, stream, rays6, flags, offsets, n, kept_rays6, kept_index);
+    return hipGetLastError();
+}
+
 hipError_t launch_photons_from_paths(hipStream_t stream, const rtg_path *paths, uint32_t n_paths, const double *dirs2,
-                                     const rtg_light *lights, uint64_t first_ray, uint64_t count_per_light, uint32_t *flags,
-                                     uint32_t *offsets, void *temp, size_t temp_bytes, uint64_t room, rtg_photon *out) {
+                                     const uint32_t *ray_index, const rtg_light *lights, uint64_t first_ray,
+                                     uint64_t count_per_light, uint32_t *flags, uint32_t *offsets, void *temp,
+                                     size_t temp_bytes, uint64_t room, rtg_photon *out) {
     if (n_paths == 0) return hipSuccess;
     const uint32_t blocks = (n_paths + 255) / 256;
     hipLaunchKernelGGL(k_photon_flags, dim3(blocks), dim3(256), 0, stream, paths, n_paths, flags);
     hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, flags, offsets, 0u, (size_t)n_paths, rocprim::plus<uint32_t>(), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_photon_write, dim3(blocks), dim3(256), 0, stream, paths, n_paths, offsets, dirs2, lights, first_ray,
-                       count_per_light, room, out);
+    hipLaunchKernelGGL(k_photon_write, dim3(blocks), dim3(256), 0, stream, paths, n_paths, offsets, dirs2, ray_index, lights,
+                       first_ray, count_per_light, room, out);
     return hipGetLastError();
 }
 

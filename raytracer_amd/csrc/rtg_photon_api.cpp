@@ -164,7 +164,8 @@ int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, c
     if (n_rays == 0) return RTG_OK;
     const void *d_lights = nullptr;
     if ((rc = api_input(ctx, "photon_lights", lights, (size_t)n_lights * sizeof(rtg_light), &d_lights)) != RTG_OK) return rc;
-    const uint64_t batch = 1ull << 19;                       // rays per rtg_trace_paths call (1.1 GB of path records at depth 4)
+    const uint64_t batch = 1ull << ctx->photon_batch_log2;   // directions per batch (option "photon_batch")
+    const uint64_t paths_batch = std::min<uint64_t>(batch, 1ull << 20);   // rays per rtg_trace_paths call (2.3 GB of path records at depth 4)
     const uint64_t per_ray = (1ull << max_depth) - 1;        // paths a ray can have
     // ZenithY::into_normal (src/geo/sphere.rs:29-34): the cosine and the sine of every zenith come from the host's
     // libm, as two calls, spread over the host's cores; they go to the device together with the direction itself
@@ -228,8 +229,7 @@ int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, c
                 make_batch(next_first, dst);
             }
         }
-        void *d_paths = nullptr, *d_staged = nullptr, *d_rays = nullptr, *d_dirs = nullptr;
-        if ((rc = api_scratch(ctx, "photon_paths", (size_t)(m * per_ray) * sizeof(rtg_path), &d_paths)) != RTG_OK) return rc;
+        void *d_staged = nullptr, *d_rays = nullptr, *d_dirs = nullptr;
         if (!dirs_on_device && (rc = api_scratch(ctx, "photon_staged", (size_t)m * per_dir * sizeof(double), &d_staged)) != RTG_OK) return rc;
         if ((rc = api_scratch(ctx, "photon_rays", (size_t)m * 6 * sizeof(double), &d_rays)) != RTG_OK) return rc;
         if ((rc = api_scratch(ctx, "photon_dirs", (size_t)m * 2 * sizeof(double), &d_dirs)) != RTG_OK) return rc;
@@ -244,51 +244,76 @@ int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, c
         else
             HIP_TRY(ctx, launch_photon_rays(ctx->stream, (const double *)d_staged, (uint32_t)m, (const rtg_light *)d_lights, first,
                                             count_per_light, (double *)d_rays, (double *)d_dirs));
-        uint64_t n_paths = 0;
-        if ((rc = rtg_trace_paths(scene, (const double *)d_rays, m, max_depth, (rtg_path *)d_paths, m * per_ray, &n_paths)) != RTG_OK)
-            return rc;
-        if (n_paths == 0) continue;
-        void *flags = nullptr, *offsets = nullptr, *temp = nullptr, *d_out = nullptr;
-        const size_t temp_bytes = photon_scan_temp_bytes((uint32_t)n_paths);
-        if ((rc = api_scratch(ctx, "photon_flags", (size_t)n_paths * sizeof(uint32_t), &flags)) != RTG_OK) return rc;
-        if ((rc = api_scratch(ctx, "photon_offsets", (size_t)n_paths * sizeof(uint32_t), &offsets)) != RTG_OK) return rc;
-        if ((rc = api_scratch(ctx, "photon_scan_temp", temp_bytes, &temp)) != RTG_OK) return rc;
-        // a batch writes only what still fits the caller's room
-        const uint64_t room = sink.grow ? n_paths : (sink.capacity > total ? std::min<uint64_t>(sink.capacity - total, n_paths) : 0);
-        if ((rc = api_scratch(ctx, "photon_out", (size_t)std::max<uint64_t>(room, 1) * sizeof(rtg_photon), &d_out)) != RTG_OK) return rc;
-        HIP_TRY(ctx, launch_photons_from_paths(ctx->stream, (const rtg_path *)d_paths, (uint32_t)n_paths, (const double *)d_dirs,
-                                               (const rtg_light *)d_lights, first, count_per_light, (uint32_t *)flags,
-                                               (uint32_t *)offsets, temp, temp_bytes, room, (rtg_photon *)d_out));
+        // The rays that can make photons at all: first hits of the whole batch (hit records only), then the rays whose
+        // hit lies on a refracting object, packed in their order.  In the reference's scenes that is a few percent of
+        // the directions, and only they go through the path records.
+        void *d_hits = nullptr, *first_flags = nullptr, *first_offsets = nullptr, *first_temp = nullptr, *d_kept = nullptr,
+             *d_index = nullptr;
+        const size_t first_temp_bytes = photon_scan_temp_bytes((uint32_t)m);
+        if ((rc = api_scratch(ctx, "photon_first_hits", (size_t)m * sizeof(rtg_hit), &d_hits)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "photon_first_flags", (size_t)m * sizeof(uint32_t), &first_flags)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "photon_first_offsets", (size_t)m * sizeof(uint32_t), &first_offsets)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "photon_first_temp", first_temp_bytes, &first_temp)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "photon_kept_rays", (size_t)m * 6 * sizeof(double), &d_kept)) != RTG_OK) return rc;
+        if ((rc = api_scratch(ctx, "photon_kept_index", (size_t)m * sizeof(uint32_t), &d_index)) != RTG_OK) return rc;
+        if ((rc = api_trace_device(scene, (const double *)d_rays, m, (rtg_hit *)d_hits)) != RTG_OK) return rc;
+        HIP_TRY(ctx, launch_photon_first_filter(ctx->stream, scene->dev, (const rtg_hit *)d_hits, (const double *)d_rays, (uint32_t)m,
+                                                (uint32_t *)first_flags, (uint32_t *)first_offsets, first_temp, first_temp_bytes,
+                                                (double *)d_kept, (uint32_t *)d_index));
         uint32_t last[2] = {0, 0};                           // offsets[n - 1], flags[n - 1]
-        HIP_TRY(ctx, hipMemcpyAsync(&last[0], (const uint32_t *)offsets + (n_paths - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(&last[1], (const uint32_t *)flags + (n_paths - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&last[0], (const uint32_t *)first_offsets + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&last[1], (const uint32_t *)first_flags + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        const uint64_t made = (uint64_t)last[0] + last[1];
-        if (sink.grow) {
-            if (total + made > sink.held_capacity) {
-                const uint64_t want = std::max<uint64_t>({total + made, sink.held_capacity * 2, (uint64_t)1 << 16});
-                void *bigger = nullptr;
-                HIP_TRY(ctx, hipMalloc(&bigger, (size_t)want * sizeof(rtg_photon)));
-                hipError_t e = total ? hipMemcpyAsync(bigger, sink.held, (size_t)total * sizeof(rtg_photon), hipMemcpyDeviceToDevice, ctx->stream)
-                                     : hipSuccess;
-                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-                if (e != hipSuccess) {
-                    (void)hipFree(bigger);
-                    (void)hipGetLastError();
-                    return api_fail(ctx, RTG_E_HIP, "photon pass: %s", hipGetErrorString(e));
+        const uint64_t kept = (uint64_t)last[0] + last[1];
+        for (uint64_t part = 0; part < kept; part += paths_batch) {
+            const uint64_t k = std::min(paths_batch, kept - part);
+            void *d_paths = nullptr;
+            if ((rc = api_scratch(ctx, "photon_paths", (size_t)(k * per_ray) * sizeof(rtg_path), &d_paths)) != RTG_OK) return rc;
+            uint64_t n_paths = 0;
+            if ((rc = rtg_trace_paths(scene, (const double *)d_kept + part * 6, k, max_depth, (rtg_path *)d_paths, k * per_ray, &n_paths)) != RTG_OK)
+                return rc;
+            if (n_paths == 0) continue;
+            void *flags = nullptr, *offsets = nullptr, *temp = nullptr, *d_out = nullptr;
+            const size_t temp_bytes = photon_scan_temp_bytes((uint32_t)n_paths);
+            if ((rc = api_scratch(ctx, "photon_flags", (size_t)n_paths * sizeof(uint32_t), &flags)) != RTG_OK) return rc;
+            if ((rc = api_scratch(ctx, "photon_offsets", (size_t)n_paths * sizeof(uint32_t), &offsets)) != RTG_OK) return rc;
+            if ((rc = api_scratch(ctx, "photon_scan_temp", temp_bytes, &temp)) != RTG_OK) return rc;
+            // a batch writes only what still fits the caller's room
+            const uint64_t room = sink.grow ? n_paths : (sink.capacity > total ? std::min<uint64_t>(sink.capacity - total, n_paths) : 0);
+            if ((rc = api_scratch(ctx, "photon_out", (size_t)std::max<uint64_t>(room, 1) * sizeof(rtg_photon), &d_out)) != RTG_OK) return rc;
+            HIP_TRY(ctx, launch_photons_from_paths(ctx->stream, (const rtg_path *)d_paths, (uint32_t)n_paths, (const double *)d_dirs,
+                                                   (const uint32_t *)d_index + part, (const rtg_light *)d_lights, first, count_per_light,
+                                                   (uint32_t *)flags, (uint32_t *)offsets, temp, temp_bytes, room, (rtg_photon *)d_out));
+            HIP_TRY(ctx, hipMemcpyAsync(&last[0], (const uint32_t *)offsets + (n_paths - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(&last[1], (const uint32_t *)flags + (n_paths - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            const uint64_t made = (uint64_t)last[0] + last[1];
+            if (sink.grow) {
+                if (total + made > sink.held_capacity) {
+                    const uint64_t want = std::max<uint64_t>({total + made, sink.held_capacity * 2, (uint64_t)1 << 16});
+                    void *bigger = nullptr;
+                    HIP_TRY(ctx, hipMalloc(&bigger, (size_t)want * sizeof(rtg_photon)));
+                    hipError_t e = total ? hipMemcpyAsync(bigger, sink.held, (size_t)total * sizeof(rtg_photon), hipMemcpyDeviceToDevice, ctx->stream)
+                                         : hipSuccess;
+                    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                    if (e != hipSuccess) {
+                        (void)hipFree(bigger);
+                        (void)hipGetLastError();
+                        return api_fail(ctx, RTG_E_HIP, "photon pass: %s", hipGetErrorString(e));
+                    }
+                    if (sink.held) (void)hipFree(sink.held);
+                    sink.held = bigger;
+                    sink.held_capacity = want;
                 }
-                if (sink.held) (void)hipFree(sink.held);
-                sink.held = bigger;
-                sink.held_capacity = want;
+                HIP_TRY(ctx, hipMemcpyAsync((rtg_photon *)sink.held + total, d_out, (size_t)made * sizeof(rtg_photon), hipMemcpyDeviceToDevice,
+                                            ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the scratch is reused by the next batch
+            } else if (total + made <= sink.capacity) {
+                if ((rc = copy_out(ctx, sink.user + total, d_out, (size_t)made * sizeof(rtg_photon))) != RTG_OK) return rc;
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the scratch is reused by the next batch
             }
-            HIP_TRY(ctx, hipMemcpyAsync((rtg_photon *)sink.held + total, d_out, (size_t)made * sizeof(rtg_photon), hipMemcpyDeviceToDevice,
-                                        ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the scratch is reused by the next batch
-        } else if (total + made <= sink.capacity) {
-            if ((rc = copy_out(ctx, sink.user + total, d_out, (size_t)made * sizeof(rtg_photon))) != RTG_OK) return rc;
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the scratch is reused by the next batch
+            total += made;
         }
-        total += made;
     }
     *n_total = total;
     return RTG_OK;

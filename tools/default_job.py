@@ -5,7 +5,7 @@ and 5 Newton steps per path point; every frame is written as the reference's thr
 (the caller's side in the reference: Sphere::fibonacci_sphere), photon pass + k-d tree, pixel pass, image encoding.
 The CPU side is the oracle on a reduced photon count (its photon pass is linear in the count).
 Usage: tools/default_job.py [frames (default 5)] [photons per light (default 10000000)] [oracle photons per light (default 200000)]
-       [host: photon directions and their sin / cos on the host instead of the GPU]"""
+       [host: photon directions and their sin / cos on the host instead of the GPU] [batch=N: option photon_batch]"""
 import os
 import sys
 import time
@@ -23,6 +23,9 @@ oracle_count = int(sys.argv[3]) if len(sys.argv) > 3 else 200_000
 W = H = 300
 
 ctx = rtg.Context(0)
+for a in sys.argv[4:]:
+    if a.startswith("batch="):
+        ctx.set_option("photon_batch", int(a[6:]))
 ON_HOST = "host" in sys.argv[4:]              # directions and their sin / cos on the host (bit-exact with the oracle)
 rtg.render_scene_builder_photons(ctx, 0, W, H, min(count, 1_000_000), photons_on_host="host" in sys.argv[4:])          # warm-up: scratch buffers, first launches
 rows = []
