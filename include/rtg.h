@@ -256,6 +256,8 @@ int rtg_ctx_synchronize(rtg_ctx *ctx);
  *                     as it does between the platforms the reference runs on); 1 = host libm (default)
  *   "photon_batch" 12..24 = log2 of the photon directions handled per batch (default 23): a batch holds 140 bytes per
  *                     direction in scratch memory and costs a fixed number of launches and waits for the host
+ *   "kd_finish" 2 = the photon map's k-d tree build finishes ranges of at most 1024 photons in one launch, a workgroup
+ *                   per range (default); 1 = every level as device-wide passes (same tree, slower: for comparison)
  *   "time_kernels" 2 = record each persistent-kernel launch's execution window (rtg_ctx_kernel_time), 1 = off */
 int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value);
 /* With option "time_kernels" = 2 every persistent-kernel launch behind rtg_render_primary / rtg_trace records its
@@ -438,6 +440,10 @@ void rtg_photon_map_destroy(rtg_photon_map *map);
  * photons at exactly the same distance is reported is not defined (in the reference it depends on the heap). */
 int rtg_photon_map_nearest(rtg_photon_map *map, const double *queries3, uint64_t n_queries, uint32_t k,
                            uint32_t *out_index, double *out_distance);
+/* The tree as the reference holds it: `KdTree` is its entry array in tree order (src/tree/kd_tree.rs:74-95,
+ * src/tree/seq_tree.rs:36-49: the root of a range sits in its middle, the two halves on either side).  out_index[p]
+ * (n_photons values, host or device memory) is the index of the photon at position p of that array. */
+int rtg_photon_map_order(rtg_photon_map *map, uint32_t *out_index);
 
 /* `compute_indirect_irrad` (src/render/renderer.rs:206-265) for n surface points: for each of the photon_samples
  * nearest photons the emission direction is corrected by newton_steps Newton steps so that the photon's path --

@@ -600,6 +600,10 @@ int rtg_ctx_set_option(rtg_ctx *ctx, const char *key, int64_t value) try {
         ctx->photon_batch_log2 = (uint32_t)value;
         return RTG_OK;
     }
+    if (std::strcmp(key, "kd_finish") == 0) {
+        ctx->kd_finish_in_lds = value > 1;       // 2 = on (default), 1 = every level as device-wide passes
+        return RTG_OK;
+    }
     if (std::strcmp(key, "comm_loopback") == 0) {
         ctx->comm_loopback = value > 1;          // 2 = on, 1 = off
         return RTG_OK;

@@ -42,6 +42,9 @@ struct rtg_ctx {
     // scratch memory (rays, first hits, the packed rays that can make photons) and costs a fixed number of launches
     // and a few waits for the host; the path records are made for at most 2^20 of the packed rays at a time.
     uint32_t photon_batch_log2 = 23;
+    // option "kd_finish": the photon map's k-d tree build hands ranges of at most 1024 photons to one workgroup each,
+    // which finishes them in LDS in a single launch (same tree as the level-by-level passes; off for comparison).
+    bool kd_finish_in_lds = true;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, idle_events;
     // rtg_render_frame renders a frame of an opaque scene as two row bands on two streams (option "frame_bands"):
     // `side` is an internal context (own stream and scratch) for the second band, joined back by events

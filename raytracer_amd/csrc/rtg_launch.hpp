@@ -133,7 +133,9 @@ hipError_t launch_kd_nearest(hipStream_t stream, const void *nodes, uint32_t n_n
 // holds kd_build_scratch_bytes(n) bytes; *summary points at two words inside it, valid once the stream has drained:
 // the longest photon path (capped at 3) and the index of the first photon with a NaN coordinate (or 0xFFFFFFFF).
 size_t kd_build_scratch_bytes(uint32_t n);
-hipError_t build_kd_device(hipStream_t stream, const rtg_photon *photons, uint32_t n, void *scratch, void *nodes, uint32_t **summary);
+// finish_in_lds: ranges of at most 1024 photons are finished by one workgroup each in a single launch (same tree).
+hipError_t build_kd_device(hipStream_t stream, const rtg_photon *photons, uint32_t n, void *scratch, void *nodes, uint32_t **summary,
+                           bool finish_in_lds = true);
 // The rays of a batch of emission directions and their (zenith, y) pairs from `staged` (cos zenith, sin zenith,
 // zenith, y per direction, device memory).
 hipError_t launch_photon_rays(hipStream_t stream, const double *staged, uint32_t n, const rtg_light *lights, uint64_t first_ray,

@@ -164,8 +164,6 @@ int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, c
     if (n_rays == 0) return RTG_OK;
     const void *d_lights = nullptr;
     if ((rc = api_input(ctx, "photon_lights", lights, (size_t)n_lights * sizeof(rtg_light), &d_lights)) != RTG_OK) return rc;
-    const uint64_t batch = 1ull << ctx->photon_batch_log2;   // directions per batch (option "photon_batch")
-    const uint64_t paths_batch = std::min<uint64_t>(batch, 1ull << 20);   // rays per rtg_trace_paths call (2.3 GB of path records at depth 4)
     const uint64_t per_ray = (1ull << max_depth) - 1;        // paths a ray can have
     // ZenithY::into_normal (src/geo/sphere.rs:29-34): the cosine and the sine of every zenith come from the host's
     // libm, as two calls, spread over the host's cores; they go to the device together with the direction itself
@@ -183,6 +181,10 @@ int emit_photons(rtg_scene *scene, const rtg_light *lights, uint32_t n_lights, c
     // the rays takes cosine and sine itself.
     const bool trig_device = ctx->photon_trig_device || fibonacci_seed != nullptr;
     const bool dirs_on_device = fibonacci_seed != nullptr || (trig_device && api_is_device_pointer(dirs2));
+    // directions per batch (option "photon_batch"); directions that come from the host are staged batch by batch while
+    // the GPU traces the batch before, which wants more and smaller batches
+    const uint64_t batch = std::min<uint64_t>(1ull << ctx->photon_batch_log2, dirs_on_device ? ~0ull : 1ull << 20);
+    const uint64_t paths_batch = std::min<uint64_t>(batch, 1ull << 20);   // rays per rtg_trace_paths call (2.3 GB of path records at depth 4)
     const size_t per_dir = trig_device ? 2 : 4;
     const size_t batch_doubles = (size_t)std::min(batch, n_rays) * per_dir;
     if (!dirs_on_device) {
@@ -345,7 +347,7 @@ int map_over(rtg_ctx *ctx, void *d_photons, uint64_t n_photons, rtg_photon_map *
     uint32_t *d_summary = nullptr;
     uint32_t summary[2] = {0, 0xFFFFFFFFu};
     hipError_t e = hipMalloc(&m->d_nodes, (size_t)n * sizeof(KdNode));
-    if (e == hipSuccess) e = build_kd_device(ctx->stream, (const rtg_photon *)m->d_photons, n, scratch, m->d_nodes, &d_summary);
+    if (e == hipSuccess) e = build_kd_device(ctx->stream, (const rtg_photon *)m->d_photons, n, scratch, m->d_nodes, &d_summary, ctx->kd_finish_in_lds);
     if (e == hipSuccess) e = hipMemcpyAsync(summary, d_summary, sizeof(summary), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -512,6 +514,22 @@ int rtg_photon_map_nearest(rtg_photon_map *map, const double *queries3, uint64_t
     return RTG_OK;
 } catch (...) {
     return api_caught(map ? map->ctx : nullptr, "rtg_photon_map_nearest");
+}
+
+int rtg_photon_map_order(rtg_photon_map *map, uint32_t *out_index) try {
+    int rc = check_map_call(map);
+    if (rc != RTG_OK) return rc;
+    rtg_ctx *ctx = map->ctx;
+    if (map->n == 0) return RTG_OK;
+    if (!out_index) return api_fail(ctx, RTG_E_INVALID, "rtg_photon_map_order: out_index is null");
+    const bool on_device = api_is_device_pointer(out_index);
+    HIP_TRY(ctx, hipMemcpy2DAsync(out_index, sizeof(uint32_t), (const char *)map->d_nodes + offsetof(KdNode, value), sizeof(KdNode),
+                                  sizeof(uint32_t), (size_t)map->n, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                  ctx->stream));
+    if (!on_device) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTG_OK;
+} catch (...) {
+    return api_caught(map ? map->ctx : nullptr, "rtg_photon_map_order");
 }
 
 int rtg_indirect_irrad(rtg_scene *scene, rtg_photon_map *map, const rtg_point *points, uint64_t n_points, uint32_t photon_samples,

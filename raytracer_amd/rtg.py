@@ -154,6 +154,7 @@ _sig(lib.rtg_photon_map_emit_fibonacci, C.c_int, _vp, _vp, C.c_uint32, C.c_uint6
      C.POINTER(C.c_uint64))
 _sig(lib.rtg_photon_map_destroy, None, _vp)
 _sig(lib.rtg_photon_map_nearest, C.c_int, _vp, _vp, C.c_uint64, C.c_uint32, _vp, _vp)
+_sig(lib.rtg_photon_map_order, C.c_int, _vp, _vp)
 _sig(lib.rtg_render_frame_photons, C.c_int, _vp, C.POINTER(View), _vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_double,
      C.c_uint32, C.c_uint32, Rect, C.c_uint32, _vp, _vp)
 _sig(lib.rtg_indirect_irrad, C.c_int, _vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, _vp)
@@ -576,6 +577,12 @@ class PhotonMap:
         dist = np.empty((q.shape[0], k), dtype=np.float64)
         self.ctx._check(lib.rtg_photon_map_nearest(self._h, _ptr(q), q.shape[0], k, _ptr(idx), _ptr(dist)))
         return idx, dist
+
+    def order(self):
+        """The photon index at every position of the tree's entry array (KdTree's own order)."""
+        out = np.empty(self.n, dtype=np.uint32)
+        self.ctx._check(lib.rtg_photon_map_order(self._h, _ptr(out) if self.n else None))
+        return out
 
     def nearest_raw(self, queries_ptr, n, k, index_ptr, distance_ptr):
         self.ctx._check(lib.rtg_photon_map_nearest(self._h, _ptr(queries_ptr), n, k, _ptr(index_ptr), _ptr(distance_ptr)))

@@ -27,7 +27,7 @@ def _restore_ctx_options(request):
     yield
     if "gpu_ctx" in request.fixturenames:
         ctx = request.getfixturevalue("gpu_ctx")
-        for key, value in (("traversal", 2), ("pretest", 2), ("frame_bands", 2), ("time_kernels", 1), ("stats", 1), ("sort_rays", 1), ("keep_state", 1), ("comm_loopback", 1), ("photon_trig", 1),
+        for key, value in (("traversal", 2), ("pretest", 2), ("frame_bands", 2), ("time_kernels", 1), ("stats", 1), ("sort_rays", 1), ("keep_state", 1), ("comm_loopback", 1), ("photon_trig", 1), ("kd_finish", 2), ("photon_batch", 23),
                            ("tri_min", 20), ("obj_min", 4), ("patch_tri_min", 24), ("max_blocks", 0)):
             ctx.set_option(key, value)
         ctx.set_stream(None)

@@ -67,6 +67,7 @@ def test_null_arguments_are_errors_not_crashes():
     assert rtg.lib.rtg_photon_map_create(None, None, 0, None) == -1
     assert rtg.lib.rtg_photon_map_emit(None, None, 0, None, 0, 4, None, None) == -1
     assert rtg.lib.rtg_photon_map_nearest(None, None, 0, 1, None, None) == -1
+    assert rtg.lib.rtg_photon_map_order(None, None) == -1
     assert rtg.lib.rtg_indirect_irrad(None, None, None, 0, 3, 5, 1e-5, None) == -1
     assert rtg.lib.rtg_render_frame_photons(None, None, None, 0, None, 3, 5, 1e-5, 1, 1, rtg.Rect(0, 0, 1, 1), 4, None, None) == -1
     assert rtg.lib.rtg_render_primary_static(None, None, 1, 1, rtg.Rect(0, 0, 1, 1), None) == -1

@@ -105,6 +105,45 @@ def test_nearest_photons_every_small_size(gpu_ctx):
         pm.close()
 
 
+def test_tree_finished_by_workgroups_is_the_tree_of_the_level_passes(gpu_ctx):
+    """The build hands ranges of at most 1024 photons to one workgroup each (option kd_finish, the default); with the
+    option off every level is a device-wide pass.  Same entry order (src/tree/seq_tree.rs:36-49), same answers, bit
+    for bit -- sizes around the hand-over, coincident photons, photons crowded on a plane."""
+    rng = np.random.default_rng(23)
+    for n in (1, 2, 3, 17, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 5000, 70_001, 441_112):
+        ph = np.zeros(n, dtype=rtg.PHOTON_DTYPE)
+        pos = rng.normal(size=(n, 3))
+        if n > 100:
+            pos[:, 1] = np.where(rng.random(n) < 0.5, -0.5, pos[:, 1])
+            pos[40:90] = pos[40]
+            pos[::7] = np.round(pos[::7] * 4.0) / 4.0
+        ph["position"] = pos
+        q = np.concatenate([rng.normal(size=(2000, 3)), pos[:200]])
+        got = []
+        for mode in (2, 1):
+            gpu_ctx.set_option("kd_finish", mode)
+            pm = rtg.PhotonMap(gpu_ctx, ph)
+            got.append((pm.order(), *pm.nearest(q, 5)))
+            pm.close()
+        gpu_ctx.set_option("kd_finish", 2)
+        assert np.array_equal(np.sort(got[0][0]), np.arange(n)), n
+        for a, b in zip(*got):
+            assert a.tobytes() == b.tobytes(), n
+        if n <= 5000:          # and the order is a k-d order: every range's middle entry splits it along some axis
+            order = got[0][0]
+            stack = [(0, n)]
+            while stack:
+                b, e = stack.pop()
+                if e - b < 2:
+                    continue
+                c = b + (e - b) // 2
+                seg = pos[order[b:e]]
+                ext = seg.max(axis=0) - seg.min(axis=0)
+                axis = 2 - int(np.argmax(ext[::-1]))             # the last of equal maxima
+                assert (pos[order[b:c], axis] <= pos[order[c], axis]).all() and (pos[order[c + 1:e], axis] >= pos[order[c], axis]).all(), (n, b, e)
+                stack += [(b, c), (c + 1, e)]
+
+
 def test_nearest_photons_large(gpu_ctx):
     rng = np.random.default_rng(11)
     n = 300_000
