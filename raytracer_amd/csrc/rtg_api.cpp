@@ -319,56 +319,123 @@ int layout_tree(rtg_ctx *ctx, const rtg_bvh *bvh, std::vector<DevNode> &ref_node
 // Takes the threaded nodes in pre-order (link = pre-order index of the node after the subtree) and gives every node
 // its position, its skip link and its pass link (DevNode::nchild) by position.  A tree in which no node has leaves
 // and children at once -- every tree the builders make -- is stored with the children of a node side by side and the
-// root last, so that pairs of siblings start at even positions and share a 64-byte half line.  The groups of the
+// root last, so that pairs of siblings start at even positions and share a 64-byte half line.  The pairs of the
 // parents in the top kThreadedTopLevels levels come first, level by level (what every ray touches sits in one
-// compact block), then the groups of all deeper parents in depth-first order.  Any other tree stays in pre-order (a
-// node with leaves goes on to its children only after its leaves, which the kernels read from the full node).  The
-// visit order is the same in every placement.
+// compact block).  Below them a binary tree is placed by 128-byte lines (threaded_pair_slots in rtg_device.hpp);
+// other trees put the groups of all deeper parents in depth-first order.  A tree with a node that has leaves and
+// children stays in pre-order (such a node goes on to its children only after its leaves, which the kernels read
+// from the full node).  The visit order is the same in every placement.
 void place_threaded(std::vector<DevNode> &thr_nodes, uint32_t &troot_out) {
     const uint32_t n = (uint32_t)thr_nodes.size();
     troot_out = 0;
     if (n == 0) return;
-    bool pure = true;
-    for (uint32_t i = 0; i < n && pure; i++) pure = !(thr_nodes[i].leaf_count != 0 && i + 1 < thr_nodes[i].link);
+    bool pure = true, binary = true;
+    for (uint32_t i = 0; i < n && pure; i++) {
+        const bool inner = i + 1 < thr_nodes[i].link;
+        pure = !(thr_nodes[i].leaf_count != 0 && inner);
+        // two children: the first child's skip link names the second, whose skip link is the parent's
+        if (inner && binary) {
+            const uint32_t second = thr_nodes[i + 1].link;
+            binary = second < thr_nodes[i].link && thr_nodes[second].link == thr_nodes[i].link;
+        }
+    }
     if (!pure || n == 1) {
         for (uint32_t i = 0; i < n; i++) thr_nodes[i].nchild = i + 1 < thr_nodes[i].link ? i + 1 : thr_nodes[i].link;
         return;
     }
-    std::vector<uint32_t> order, stack, kids, level, below;
-    order.reserve(n);
-    auto place_children_of = [&](uint32_t i) {
-        kids.clear();
-        for (uint32_t c = i + 1; c < thr_nodes[i].link; c = thr_nodes[c].link) kids.push_back(c);
-        for (uint32_t c : kids) order.push_back(c);
-    };
-    level.push_back(0);
-    for (uint32_t d = 0; d < kThreadedTopLevels && !level.empty(); d++) {      // the top levels, breadth first
-        below.clear();
-        for (uint32_t i : level) {
-            place_children_of(i);
-            for (uint32_t c : kids) below.push_back(c);
-        }
-        level.swap(below);
-    }
-    for (size_t k = level.size(); k-- > 0;) stack.push_back(level[k]);         // what hangs below them, depth first
-    while (!stack.empty()) {
-        const uint32_t i = stack.back();
-        stack.pop_back();
-        place_children_of(i);
-        for (size_t k = kids.size(); k-- > 0;) stack.push_back(kids[k]);
-    }
-    order.push_back(0);
     std::vector<uint32_t> pos(n);
-    for (uint32_t j = 0; j < n; j++) pos[order[j]] = j;
+    if (binary) {
+        // the device builder's placement, from the same counts (rtg_build.hip): pair slots by rank
+        std::vector<uint32_t> depth(n, 0), chain(n, 0);
+        std::vector<uint32_t> level_count;
+        for (uint32_t s = 0; s < n; s++) {
+            if (!(s + 1 < thr_nodes[s].link)) continue;
+            const uint32_t l = s + 1, r = thr_nodes[l].link;
+            depth[l] = depth[r] = depth[s] + 1;
+            chain[r] = r;
+            chain[l] = depth[s] >= kThreadedTopLevels ? chain[s] : l;
+            if (depth[s] < kThreadedTopLevels) {
+                if (level_count.size() <= depth[s]) level_count.resize(depth[s] + 1, 0);
+                level_count[depth[s]]++;
+            }
+        }
+        std::vector<uint32_t> level_first(level_count.size() + 1, 0);
+        for (size_t d = 0; d < level_count.size(); d++) level_first[d + 1] = level_first[d] + level_count[d];
+        PairSlots ps;
+        ps.n_top = level_first.back();
+        ps.n_pairs = (n - 1) / 2;
+        ps.n_double = ps.n_single = 0;
+        for (uint32_t s = 0; s < n; s++) {
+            if (!(s + 1 < thr_nodes[s].link) || depth[s] < kThreadedTopLevels || ((s - chain[s]) & 1u)) continue;
+            if (s + 2 < thr_nodes[s + 1].link) ps.n_double++; else ps.n_single++;
+        }
+        std::vector<uint32_t> opener(ps.n_single / 2 + 1, 0);
+        uint32_t doubles = 0, singles = 0;
+        std::vector<uint32_t> level_seen(level_count.size(), 0);
+        auto put_pair = [&](uint32_t parent, uint32_t slot) {
+            const uint32_t l = parent + 1;
+            pos[l] = 2 * slot;
+            pos[thr_nodes[l].link] = 2 * slot + 1;
+        };
+        for (uint32_t s = 0; s < n; s++) {
+            if (!(s + 1 < thr_nodes[s].link)) continue;
+            if (depth[s] < kThreadedTopLevels) {
+                put_pair(s, level_first[depth[s]] + level_seen[depth[s]]++);
+                continue;
+            }
+            if ((s - chain[s]) & 1u) continue;                    // a follower: placed with its leader
+            const bool is_double = s + 2 < thr_nodes[s + 1].link;
+            uint32_t slot;
+            if (is_double) {
+                slot = ps.double_slot(doubles, singles);
+                put_pair(s + 1, slot + 1);
+                doubles++;
+            } else {
+                uint32_t opens;
+                if (ps.single_slot(doubles, singles, slot, opens)) {
+                    if (opens != kNoOpener) opener[opens] = slot;
+                } else {
+                    slot = opener[opens] + 1;
+                }
+                singles++;
+            }
+            put_pair(s, slot);
+        }
+    } else {
+        std::vector<uint32_t> order, stack, kids, level, below;
+        order.reserve(n);
+        auto place_children_of = [&](uint32_t i) {
+            kids.clear();
+            for (uint32_t c = i + 1; c < thr_nodes[i].link; c = thr_nodes[c].link) kids.push_back(c);
+            for (uint32_t c : kids) order.push_back(c);
+        };
+        level.push_back(0);
+        for (uint32_t d = 0; d < kThreadedTopLevels && !level.empty(); d++) {      // the top levels, breadth first
+            below.clear();
+            for (uint32_t i : level) {
+                place_children_of(i);
+                for (uint32_t c : kids) below.push_back(c);
+            }
+            level.swap(below);
+        }
+        for (size_t k = level.size(); k-- > 0;) stack.push_back(level[k]);         // what hangs below them, depth first
+        while (!stack.empty()) {
+            const uint32_t i = stack.back();
+            stack.pop_back();
+            place_children_of(i);
+            for (size_t k = kids.size(); k-- > 0;) stack.push_back(kids[k]);
+        }
+        for (uint32_t j = 0; j + 1 < n; j++) pos[order[j]] = j;
+    }
+    pos[0] = n - 1;
     std::vector<DevNode> moved(n);
     api_parallel_ranges(n, (size_t)1 << 15, [&](size_t b, size_t e) {
-        for (size_t j = b; j < e; j++) {
-            const uint32_t i = order[j];
+        for (size_t i = b; i < e; i++) {
             DevNode t = thr_nodes[i];
             const uint32_t skip = t.link >= n ? n : pos[t.link];
             t.nchild = i + 1 < t.link ? pos[i + 1] : skip;
             t.link = skip;
-            moved[j] = t;
+            moved[pos[i]] = t;
         }
     });
     thr_nodes.swap(moved);

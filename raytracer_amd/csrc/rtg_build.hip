@@ -19,14 +19,13 @@
 //     used (first probed equal element wins), then the 1 % / 99 % clamp (bvh_subdivide.rs:29-38).
 //
 // Build nodes live in pre-order slots (a subtree over k triangles owns 2k-1 consecutive slots); the position of a
-// node's entry in the reference's flattened order (children after all descendants, root last) and its position in
-// the threaded arrays the traversal kernels read (siblings side by side, root last; first the pairs under the T
-// inner nodes of the top kThreadedTopLevels levels, level by level, then the pairs under all deeper inner nodes in
-// pre-order) follow from the same counts: the inner node at slot s whose triangles start at b is the (s - b)-th
-// inner node in pre-order, so a deep one is pair T + (s - b) - (top inner nodes before s), and a top one is pair
-// (top inner nodes of lower depth, or of the same depth and before s).  The children of pair g sit at 2 g and
-// 2 g + 1.  The last two kernels write the mesh slab, the reference-order node array and the leaf ->
-// source-triangle map.
+// node's entry in the reference's flattened order (children after all descendants, root last) follows from the
+// triangle counts.  Positions in the threaded arrays the traversal kernels read (siblings side by side in pair slots,
+// root last) come from ranks: first the pairs under the T inner nodes of the top kThreadedTopLevels levels, level by
+// level (rank by depth, then slot), then the pairs of all deeper inner nodes line by line as PairSlots
+// (rtg_device.hpp) lays them out, from the numbers of leaders of either kind before a leader in pre-order.  The
+// children of pair g sit at 2 g and 2 g + 1.  The last two kernels write the mesh slab, the reference-order node
+// array and the leaf -> source-triangle map.
 #include <hip/hip_runtime.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -49,6 +48,7 @@ struct BuildNode {
     uint32_t axis;           // bits 0..1 sort axis, bits 8..15 depth + 1 of an inner node of the top levels (else 0),
                              // bit 31 = last of its siblings
     uint32_t pos;            // position in the threaded arrays (set by k_place_*)
+    uint32_t chain;          // slot where this node's chain of first children starts below the top levels
 };
 
 constexpr uint64_t kSign = 0x8000000000000000ull;
@@ -112,7 +112,7 @@ __global__ void k_scatter_rank(const uint32_t *__restrict__ perm, const uint32_t
 
 __global__ void k_init(BuildNode *nodes, uint64_t *bounds, uint32_t n) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        nodes[0] = BuildNode{0u, n, 0u, 2u * n - 2u, 0u, 0x80000000u, 2u * n - 2u};
+        nodes[0] = BuildNode{0u, n, 0u, 2u * n - 2u, 0u, 0x80000000u, 2u * n - 2u, 0u};
         for (int k = 0; k < 3; k++) {
             bounds[k] = ord_of(kInf);
             bounds[3 + k] = ord_of(-kInf);
@@ -301,8 +301,8 @@ __global__ void k_split(BuildNode *__restrict__ nodes, uint64_t *__restrict__ bo
     if (split > max_split) split = max_split;
     nodes[x].split = split;
     const uint32_t l = x + 1, r = x + 2 * split;
-    nodes[l] = BuildNode{b, split, nd.base, nd.base + 2 * k - 4, 0u, 0u, 0u};
-    nodes[r] = BuildNode{b + split, k - split, nd.base + 2 * split - 2, nd.base + 2 * k - 3, 0u, 0x80000000u, 0u};
+    nodes[l] = BuildNode{b, split, nd.base, nd.base + 2 * k - 4, 0u, 0u, 0u, level >= kThreadedTopLevels ? nd.chain : l};
+    nodes[r] = BuildNode{b + split, k - split, nd.base + 2 * split - 2, nd.base + 2 * k - 3, 0u, 0x80000000u, 0u, r};
     for (int c = 0; c < 3; c++) {
         bounds[(size_t)l * 6 + c] = ord_of(kInf);
         bounds[(size_t)l * 6 + 3 + c] = ord_of(-kInf);
@@ -313,10 +313,9 @@ __global__ void k_split(BuildNode *__restrict__ nodes, uint64_t *__restrict__ bo
     if (k - split >= 2) next_active[atomicAdd(next_count, 1u)] = r;
 }
 
-// Positions in the threaded arrays.  k_top_flag marks the inner nodes of the top levels; after an exclusive scan of
-// the marks (`before`), k_top_list packs their (depth, slot) keys in slot order, k_place_top ranks every key among
-// all of them (a few thousand at most) and k_place_deep counts pre-order ranks; both write the two children's
-// positions.
+// Positions in the threaded arrays, top block.  k_top_flag marks the inner nodes of the top levels; after an
+// exclusive scan of the marks (`before`), k_top_list packs their (depth, slot) keys in slot order and k_place_top
+// ranks every key among all of them (a few thousand at most) and writes the two children's positions.
 __global__ void k_top_flag(const BuildNode *__restrict__ nodes, uint32_t n_nodes, uint32_t *__restrict__ flag) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < n_nodes) flag[s] = (nodes[s].axis & 0xFF00u) ? 1u : 0u;
@@ -336,15 +335,51 @@ __global__ void k_place_top(BuildNode *__restrict__ nodes, const uint64_t *__res
     nodes[s + 1].pos = 2 * g;
     nodes[s + 2 * nodes[s].split].pos = 2 * g + 1;
 }
-__global__ void k_place_deep(BuildNode *__restrict__ nodes, uint32_t n_nodes, const uint32_t *__restrict__ flag,
-                             const uint32_t *__restrict__ before, uint32_t n_top) {
+// Leaders below the top levels: the inner nodes at an even distance along their chain of first children.  A leader
+// whose first child has children is a double (high word), any other a single (low word).
+__device__ inline bool deep_leader(const BuildNode &nd, uint32_t s) {
+    return nd.count >= 2 && !(nd.axis & 0xFF00u) && ((s - nd.chain) & 1u) == 0;
+}
+__global__ void k_leader_flags(const BuildNode *__restrict__ nodes, uint32_t n_nodes, uint64_t *__restrict__ flag) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_nodes || flag[s]) return;
+    if (s >= n_nodes) return;
     const BuildNode nd = nodes[s];
-    if (nd.count < 2) return;
-    const uint32_t g = n_top + (s - nd.begin) - before[s];
-    nodes[s + 1].pos = 2 * g;
-    nodes[s + 2 * nd.split].pos = 2 * g + 1;
+    uint64_t f = 0;
+    if (deep_leader(nd, s)) f = nd.split >= 2 ? 1ull << 32 : 1ull;      // split = triangles of the first child
+    flag[s] = f;
+}
+// before[s]: doubles (high word) and singles (low word) before slot s.  Doubles, the singles that open a line and
+// the singles with a slot of their own are placed here; the singles that join a line in k_place_joiners.
+__global__ void k_place_leaders(BuildNode *__restrict__ nodes, uint32_t n_nodes, const uint64_t *__restrict__ before,
+                                PairSlots ps, uint32_t *__restrict__ opener) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_nodes) return;
+    const BuildNode nd = nodes[s];
+    if (!deep_leader(nd, s)) return;
+    const uint32_t doubles = (uint32_t)(before[s] >> 32), singles = (uint32_t)before[s];
+    uint32_t slot, opens;
+    if (nd.split >= 2) {
+        slot = ps.double_slot(doubles, singles);
+        nodes[s + 2].pos = 2 * (slot + 1);                                   // the follower's children
+        nodes[s + 1 + 2 * nodes[s + 1].split].pos = 2 * (slot + 1) + 1;
+    } else {
+        if (!ps.single_slot(doubles, singles, slot, opens)) return;
+        if (opens != kNoOpener) opener[opens] = slot;
+    }
+    nodes[s + 1].pos = 2 * slot;
+    nodes[s + 2 * nd.split].pos = 2 * slot + 1;
+}
+__global__ void k_place_joiners(BuildNode *__restrict__ nodes, uint32_t n_nodes, const uint64_t *__restrict__ before,
+                                PairSlots ps, const uint32_t *__restrict__ opener) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_nodes) return;
+    const BuildNode nd = nodes[s];
+    if (!deep_leader(nd, s) || nd.split >= 2) return;
+    uint32_t slot, opens;
+    if (ps.single_slot((uint32_t)(before[s] >> 32), (uint32_t)before[s], slot, opens)) return;
+    slot = opener[opens] + 1;
+    nodes[s + 1].pos = 2 * slot;
+    nodes[s + 2 * nd.split].pos = 2 * slot + 1;
 }
 
 // Node outputs: the threaded node and its single-precision companion at the node's threaded position (skip link =
@@ -600,7 +635,31 @@ hipError_t build_subdivide_device(hipStream_t stream, const rtg_tri *d_tris, uin
         RTG_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_place_top, dim3(grid_for(n_top)), dim3(256), 0, stream, nodes, list, n_top);
         RTG_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_place_deep, dim3(gn), dim3(256), 0, stream, nodes, n_nodes, flag, before, n_top);
+        // below the top block: leaders counted in pre-order, then placed line by line
+        uint64_t *lflag, *lbefore;
+        RTG_TRY(buf.get((size_t)n_nodes * 8, (void **)&lflag));
+        RTG_TRY(buf.get((size_t)n_nodes * 8, (void **)&lbefore));
+        hipLaunchKernelGGL(k_leader_flags, dim3(gn), dim3(256), 0, stream, nodes, n_nodes, lflag);
+        RTG_TRY(hipGetLastError());
+        size_t lbytes = 0;
+        RTG_TRY(rocprim::exclusive_scan(nullptr, lbytes, lflag, lbefore, (uint64_t)0, (size_t)n_nodes, rocprim::plus<uint64_t>(), stream));
+        void *ltemp = temp;
+        if (lbytes > temp_bytes) RTG_TRY(buf.get(lbytes, &ltemp));
+        RTG_TRY(rocprim::exclusive_scan(ltemp, lbytes, lflag, lbefore, (uint64_t)0, (size_t)n_nodes, rocprim::plus<uint64_t>(), stream));
+        uint64_t last[2];
+        RTG_TRY(hipMemcpyAsync(&last[0], lflag + (n_nodes - 1), 8, hipMemcpyDeviceToHost, stream));
+        RTG_TRY(hipMemcpyAsync(&last[1], lbefore + (n_nodes - 1), 8, hipMemcpyDeviceToHost, stream));
+        RTG_TRY(hipStreamSynchronize(stream));
+        PairSlots ps;
+        ps.n_top = n_top;
+        ps.n_pairs = n - 1;
+        ps.n_double = (uint32_t)((last[0] + last[1]) >> 32);
+        ps.n_single = (uint32_t)(last[0] + last[1]);
+        uint32_t *opener = active_a;                          // n / 2 + 1 words: a line of singles per two singles
+        hipLaunchKernelGGL(k_place_leaders, dim3(gn), dim3(256), 0, stream, nodes, n_nodes, (const uint64_t *)lbefore, ps, opener);
+        RTG_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_place_joiners, dim3(gn), dim3(256), 0, stream, nodes, n_nodes, (const uint64_t *)lbefore, ps,
+                           (const uint32_t *)opener);
         RTG_TRY(hipGetLastError());
     }
 

@@ -70,9 +70,15 @@ __device__ __forceinline__ bool lanes_of(uint64_t mask) { return __builtin_amdgc
 // gain from the extra latency hiding; an incoherent batch against a tree larger than the caches is bound by HBM
 // traffic, which more rays in flight only raise (measured: 64 M bench_mesh rays against 10 M triangles, 28.7 ms at
 // four waves, 31.1 ms at five).
+// kLanePairFetch: neighbouring lanes fetch their two node records together, half a record each per load (single-mesh
+// builds with the pre-test).  With unrelated rays every lane stands at a node of its own and a load touches 64
+// cache lines; the L1 looks lines up one after the other, and that rate -- not the bytes from memory -- is what bounds
+// such a batch (64 M bench_mesh rays against 10 M triangles: 26.5 -> 24.2 ms per launch).  Coherent rays share lines
+// anyway and would only pay for the exchange (-1 % on the 1080p frame).
 struct PrimarySource {
     static constexpr bool kEarlyStop = false;
     static constexpr bool kFiveWaves = true;
+    static constexpr bool kLanePairFetch = false;
     __device__ __forceinline__ double stop_time(uint64_t) const { return -kInf; }
     rtg_view view;
     uint32_t width, height;
@@ -108,6 +114,7 @@ struct PrimarySource {
 struct BatchSource {
     static constexpr bool kEarlyStop = false;
     static constexpr bool kFiveWaves = false;
+    static constexpr bool kLanePairFetch = true;
     __device__ __forceinline__ double stop_time(uint64_t) const { return -kInf; }
     const double *rays6;
     uint64_t n;
@@ -129,6 +136,7 @@ struct BatchSource {
 struct ShadowSource {
     static constexpr bool kEarlyStop = true;
     static constexpr bool kFiveWaves = true;
+    static constexpr bool kLanePairFetch = false;
     const rtg_point *points;
     const rtg_light *lights;
     uint64_t n_points;
@@ -169,6 +177,7 @@ struct ShadowSource {
 struct ShadowAndBatchSource {
     static constexpr bool kEarlyStop = true;
     static constexpr bool kFiveWaves = false;
+    static constexpr bool kLanePairFetch = false;
     ShadowSource shadow;
     BatchSource batch;
     uint64_t n_shadow;
@@ -898,6 +907,24 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                     U4 hp = (U4)((act ? slab_v : first_slab) + (uint64_t)(act ? cur : 0u) * sizeof(HotNode));
                     h0 = hp[0];
                     h1 = hp[1];
+                } else if (Source::kLanePairFetch) {
+                    // Lanes 2i and 2i+1 fetch their two records together: both read lane 2i's node in the first load
+                    // and lane 2i+1's in the second, the even lane the first 16 bytes and the odd lane the last, and
+                    // swap halves afterwards.  A load then touches 32 cache lines instead of 64, which is what the L1
+                    // charges for when every lane is at a node of its own.
+                    const uint32_t mine = (act ? cur : 0u) * (uint32_t)sizeof(HotNode);
+                    const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);
+                    const bool odd = (threadIdx.x & 1u) != 0;
+                    const uint32_t half = odd ? 16u : 0u;
+                    const vu4 a = __builtin_amdgcn_raw_buffer_load_b128(hot_rsrc, (odd ? theirs : mine) + half, 0, 0);
+                    const vu4 b = __builtin_amdgcn_raw_buffer_load_b128(hot_rsrc, (odd ? mine : theirs) + half, 0, 0);
+                    vu4 ax, bx;
+                    for (int k = 0; k < 4; k++) {
+                        ax[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[k], 0xB1, 0xF, 0xF, true);
+                        bx[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b[k], 0xB1, 0xF, 0xF, true);
+                    }
+                    h0 = odd ? bx : a;
+                    h1 = odd ? b : ax;
                 } else {
                     // one mesh: buffer loads, whose address is a scalar base plus the lane's 32-bit byte offset -- no
                     // 64-bit address arithmetic per lane (the launcher sends trees whose hot nodes span 4 GiB or more
