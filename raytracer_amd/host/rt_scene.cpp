@@ -284,7 +284,8 @@ int Renderer::pixel_costs() {
 double smpte2048_encode(double x) {
     const double M1 = 1305.0 / 8192.0, M2 = 2523.0 / 32.0;
     const double C1 = 107.0 / 128.0, C2 = 2413.0 / 128.0, C3 = 2392.0 / 128.0;
-    return std::pow((C1 + C2 * std::pow(x, M1)) / (1.0 + C3 * std::pow(x, M1)), M2);
+    const double xm = std::pow(x, M1);          // the same value in both places of render/image.rs:36-37
+    return std::pow((C1 + C2 * xm) / (1.0 + C3 * xm), M2);
 }
 
 // Rows [y0, y1) of a picture, shared among the host's cores: f(row range) for every range.

@@ -3,6 +3,8 @@
 
   tools/roofline_ceiling.py <profiles dir> <workload key> <kernel> <loads per visit> [pmc summary file] [gather file]
                             [records of the table that stands for "beyond L2": 2097152 (64 MB, default) or 33554432 (1 GB)]
+                            [gather mode of the microbenchmark: 0 (default) or 1 (lane pairs fetch each record together,
+                            as the kernel does for ray batches)]
 
 * `<dir>/tcp_gather.txt` -- output of tools/micro/tcp_gather (mode 0: every lane gathers its own 32-byte record with
   two 16-byte loads, 16 waves per CU), one line per table size: 8 KB (served by the CU's vector L1), 2 MB (the XCD's
@@ -24,10 +26,10 @@ import re
 import sys
 
 
-def gather_rates(path, beyond=2097152):
+def gather_rates(path, beyond=2097152, mode=0):
     rates = {}
     for line in open(path):
-        m = re.match(r"\s*(\d+) records, mode 0: ([\d.]+) ms", line)
+        m = re.match(r"\s*(\d+) records, mode %d: ([\d.]+) ms" % mode, line)
         if m:
             n, ms = int(m.group(1)), float(m.group(2))
             lane_loads = 1024.0 * 256 * 2000 * 2
@@ -49,14 +51,15 @@ def main():
     pmc = sys.argv[5] if len(sys.argv) > 5 else os.path.join(d, "pmc_summary.txt")
     gather = sys.argv[6] if len(sys.argv) > 6 else os.path.join(d, "tcp_gather.txt")
     beyond = int(sys.argv[7]) if len(sys.argv) > 7 else 2097152
-    r1, r2, r3 = gather_rates(gather, beyond)
+    mode = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+    r1, r2, r3 = gather_rates(gather, beyond, mode)
     c = counters(pmc)
     to_l2 = c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
     l2_miss = c["TCC_MISS_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     f1, f2, f3 = 1.0 - to_l2, to_l2 * (1.0 - l2_miss), to_l2 * l2_miss
     lane_loads_per_s = 1.0 / (f1 / r1 + f2 / r2 + f3 / r3)
     ceiling = {"workload": workload, "kernel": kernel, "loads_per_visit": loads,
-               "gather_lane_loads_per_s": {"l1": r1, "l2": r2, "beyond_l2": r3, "beyond_l2_table_records": beyond,
+               "gather_lane_loads_per_s": {"l1": r1, "l2": r2, "beyond_l2": r3, "beyond_l2_table_records": beyond, "gather_mode": mode,
                                            "source": os.path.relpath(gather)},
                "fractions": {"l1": round(f1, 5), "l2": round(f2, 5), "beyond_l2": round(f3, 5), "source": os.path.relpath(pmc)},
                "ceiling_lane_loads_per_s": lane_loads_per_s, "ceiling_visits_per_s": lane_loads_per_s / loads,

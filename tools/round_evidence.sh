@@ -20,8 +20,10 @@ tools/prof_latency.sh "$D/latency_c4" tools/c4_prof.py 1 &&
 tools/prof_latency.sh "$D/latency_c3" tools/c3_prof.py 2 &&
 tools/prof_l1.sh "$D/l1" &&
 python tools/pmc_summary.py "$O/l1" k_trace_phased > "$O/l1_path_counters.txt" &&
+tools/prof_l2.sh "$D/l2_c4" &&
+python tools/pmc_summary.py "$O/l2_c4" k_trace_phased > "$O/l2_counters_c4.txt" &&
 python tools/roofline_ceiling.py "$O" config2-1920x1080 k_trace_phased 2 > /dev/null &&
-python tools/roofline_ceiling.py "$O" config4-64Mrays-10Mtris k_trace_phased 2 "$O/pmc_summary_c4.txt" "$O/tcp_gather.txt" 33554432 > /dev/null &&
+python tools/roofline_ceiling.py "$O" config4-64Mrays-10Mtris k_trace_phased 2 "$O/pmc_summary_c4.txt" "$O/tcp_gather.txt" 33554432 1 > /dev/null &&
 python tools/roofline_ceiling.py "$O" config3-3840x2160-patches k_trace_phased 2 "$O/pmc_summary_c3.txt" > /dev/null &&
 python tools/latency_json.py "$O/latency" config2-1920x1080 k_trace_phased 5 "$O/latency.json" > /dev/null &&
 python tools/latency_json.py "$O/latency_c4" config4-64Mrays-10Mtris k_trace_phased 4 "$O/latency_c4.json" > /dev/null &&
