@@ -33,7 +33,8 @@ def _record():
 def test_ceiling_follows_from_the_microbenchmark_and_the_counters(workload, n_rays, ray_bytes, beyond, leaf_bytes, pick):
     c = bench.committed("ceiling.json", workload, "k_trace_phased")
     assert c is not None
-    r1, r2, r3 = roofline_ceiling.gather_rates(os.path.join(ROOT, c["gather_lane_loads_per_s"]["source"]), beyond)
+    r1, r2, r3 = roofline_ceiling.gather_rates(os.path.join(ROOT, c["gather_lane_loads_per_s"]["source"]), beyond,
+                                               c["gather_lane_loads_per_s"].get("gather_mode", 0))
     assert c["gather_lane_loads_per_s"]["beyond_l2_table_records"] == beyond
     assert (r1, r2, r3) == pytest.approx((c["gather_lane_loads_per_s"]["l1"], c["gather_lane_loads_per_s"]["l2"],
                                           c["gather_lane_loads_per_s"]["beyond_l2"]), rel=1e-9)
