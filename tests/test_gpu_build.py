@@ -101,6 +101,25 @@ def test_random_meshes_of_many_sizes(gpu_ctx):
             assert np.array_equal(source, host.leaf_source()), (n, quantum)
             assert nodes.tobytes() == host.nodes().tobytes(), (n, quantum)
             assert mesh.sizes() == (host.n_nodes, host.n_leaves, host.root, host.depth), (n, quantum)
+            # the positions the device builder gives the threaded nodes (pair slots by rank) make the tree the host
+            # placement makes: same answers for rays from all around, in the kernels that follow the links
+            reference = gpu_ctx.mesh(host)
+            lo, hi = host.bounds()[:3], host.bounds()[3:]
+            rays = rtg.bench_mesh_rays(np.concatenate([lo - 0.1, hi + 0.1]), 768, seed=n)
+            answers = []
+            for m in (mesh, reference):
+                sc = gpu_ctx.scene([rtg.mesh_object(m, rtg.material((0.5, 0.5, 0.5)))])
+                row = []
+                for traversal in (2, 1):
+                    gpu_ctx.set_option("traversal", traversal)
+                    row.append(sc.trace(rays, counters=True))
+                answers.append(row)
+                sc.close()
+            gpu_ctx.set_option("traversal", 2)
+            for (h_a, _, c_a), (h_b, _, c_b) in zip(*answers):
+                assert h_a.tobytes() == h_b.tobytes() and c_a.tobytes() == c_b.tobytes(), (n, quantum)
+            assert answers[0][0][0].tobytes() == answers[0][1][0].tobytes(), (n, quantum)
+            reference.close()
             mesh.close()
             host.close()
 
