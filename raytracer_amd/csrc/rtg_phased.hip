@@ -67,9 +67,9 @@ __device__ __forceinline__ bool lanes_of(uint64_t mask) { return __builtin_amdgc
 // Every source also names the time below which a hit ends the query early (stop_time): -inf for closest-hit
 // queries; a shadow ray only has to know whether anything lies before the light.
 // kFiveWaves: the source's lean kernel variant is built for five waves per SIMD.  Coherent rays (camera, shadow)
-// gain from the extra latency hiding; an incoherent batch against a tree larger than the caches is bound by HBM
-// traffic, which more rays in flight only raise (measured: 64 M bench_mesh rays against 10 M triangles, 28.7 ms at
-// four waves, 31.1 ms at five).
+// gain from the extra latency hiding; an incoherent batch against a tree larger than the caches keeps the memory
+// path busy with three waves already, and more rays in flight only make the caches miss more (measured: 64 M
+// bench_mesh rays against 10 M triangles, 26.8 ms at three waves, 26.5 ms at four, 28.7 ms at five).
 // kLanePairFetch: neighbouring lanes fetch their two node records together, half a record each per load (single-mesh
 // builds with the pre-test).  With unrelated rays every lane stands at a node of its own and a load touches 64
 // cache lines; the L1 looks lines up one after the other, and that rate -- not the bytes from memory -- is what bounds
