@@ -296,6 +296,7 @@ def test_photons_stay_on_the_device(gpu_ctx):
     pm_dev = rtg.PhotonMap(gpu_ctx, dev.data_ptr(), n=made)
     pm_host = rtg.PhotonMap(gpu_ctx, host)
     q = host["position"][::7] + 1e-3
+    assert np.array_equal(pm_dev.order(), pm_host.order())
     for k in (1, 3):
         a, b = pm_dev.nearest(q, k), pm_host.nearest(q, k)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
@@ -312,6 +313,7 @@ def test_photons_stay_on_the_device(gpu_ctx):
     pm_one.close()
     empty = scene.photon_map(_lights(lights), np.zeros((2, 0, 2)))
     assert empty.n == 0 and (empty.nearest(q[:3], 2)[0] == rtg.RTG_NONE).all()
+    assert empty.order().shape == (0,)
     empty.close()
     pm_dev.close()
     pm_host.close()
