@@ -529,6 +529,28 @@ constexpr int phased_waves(bool five_ok, bool count, bool patch, bool keep, bool
     return patch ? RTG_PHASED_WAVES_PATCH : ((!five_ok || count || keep || stats) ? RTG_PHASED_WAVES : RTG_PHASED_WAVES_LEAN);
 }
 
+// The ray source, the output arrays and the scene's object list are only looked at between objects (a new chunk, a
+// refill, a finished ray).  Read through the kernel-argument segment at those places -- behind a barrier the optimiser
+// cannot move loads across -- they do not sit in scalar registers for the whole kernel, which is at the scalar register
+// limit: what they displaced there went to vector registers and on to scratch memory (1080p frame: 80 -> 36 bytes
+// of scratch per lane, +3 %).  PhasedArgs mirrors k_trace_phased's parameter list.
+template <class Source> struct PhasedArgs {
+    DevScene s;
+    Source src;
+    uint64_t n_items;
+    uint32_t *work_counters;
+    PhasedParams prm;
+    rtg_hit *out_hits;
+    rtg_ray_counters *out_counters;
+    const rtg_hit *prim_best;
+};
+template <class Source> __device__ __forceinline__ const PhasedArgs<Source> &args_in_kernarg() {
+    typedef const char __attribute__((address_space(4))) *KPtr;
+    KPtr base = (KPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));
+    return *(const PhasedArgs<Source> *)(const char *)base;
+}
+
 template <class Source, bool COUNT, bool PATCH, bool PRE, bool KEEP, bool STATS = false>
 __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUNT, PATCH, KEEP, STATS)) void k_trace_phased(DevScene s, Source src, uint64_t n_items,
                                                           uint32_t *work_counters, PhasedParams prm,
@@ -720,13 +742,14 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                     }
                     chunk_base = (uint64_t)chunk << 6;
                     chunk_left = 64;
-                    chunk_first = src.chunk_origin(chunk);
+                    const Source &ksrc = args_in_kernarg<Source>().src;
+                    chunk_first = ksrc.chunk_origin(chunk);
                     {                       // every lane prepares one ray of the chunk
                         const DevObject &o0 = s.mesh_objects[0];
                         Ray ray;
                         uint64_t out_index;
                         uint32_t flags = 0;
-                        if (src.make(chunk_base + (threadIdx.x & 63u), ray, out_index)) {
+                        if (ksrc.make(chunk_base + (threadIdx.x & 63u), ray, out_index)) {
                             Ray in0 = inner_ray(o0, ray);
                             flags = 1u;
                             STG_D(threadIdx.x & 63u, 0) = in0.o.x;
@@ -746,7 +769,7 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                         }
                         STG_U(threadIdx.x & 63u, 3) = flags;
                         if (Source::kEarlyStop && flags != 0) {
-                            uint64_t tb = (uint64_t)__double_as_longlong(src.stop_time(chunk_base + (threadIdx.x & 63u)));
+                            uint64_t tb = (uint64_t)__double_as_longlong(ksrc.stop_time(chunk_base + (threadIdx.x & 63u)));
                             STG_U(threadIdx.x & 63u, 4) = (uint32_t)tb;
                             STG_U(threadIdx.x & 63u, 5) = (uint32_t)(tb >> 32);
                         }
@@ -767,10 +790,11 @@ __global__ __launch_bounds__(kPhasedBlock, phased_waves(Source::kFiveWaves, COUN
                             if (Source::kEarlyStop) {
                                 t_stop = __longlong_as_double((long long)(((uint64_t)STG_U(slot, 5) << 32) | STG_U(slot, 4)));
                             }
-                            uint64_t out_index = src.slot_of(item, chunk_first);
+                            const Source &rsrc = args_in_kernarg<Source>().src;
+                            uint64_t out_index = rsrc.slot_of(item, chunk_first);
                             if (need_outer) {
                                 Ray ray;
-                                (void)src.make(item, ray, out_index);
+                                (void)rsrc.make(item, ray, out_index);
                                 COLD(C_OX) = ray.o.x;
                                 COLD(C_OY) = ray.o.y;
                                 COLD(C_OZ) = ray.o.z;
