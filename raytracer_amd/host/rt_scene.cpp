@@ -6,7 +6,11 @@
 #include <chrono>
 #include <cmath>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 namespace rt {
@@ -288,28 +292,101 @@ double smpte2048_encode(double x) {
     return std::pow((C1 + C2 * xm) / (1.0 + C3 * xm), M2);
 }
 
-// Rows [y0, y1) of a picture, shared among the host's cores: f(row range) for every range.
+// Rows [y0, y1) of a picture, shared among the host's cores: f(row range) for every range.  The workers are started
+// once and kept: a frame's three small pictures are four such jobs, and starting fifteen threads for each of them
+// cost more than the encoding itself.
+namespace {
+class RowWorkers {
+  public:
+    static RowWorkers &get() {
+        static RowWorkers pool;
+        return pool;
+    }
+    unsigned size() const { return (unsigned)workers_.size() + 1; }
+    // f(first row, end row) over `parts` consecutive ranges of [0, height), on the callers' thread and the workers
+    void run(uint32_t height, unsigned parts, const std::function<void(uint32_t, uint32_t)> &f) {
+        std::lock_guard<std::mutex> one_job(job_lock_);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = &f;
+            height_ = height;
+            parts_ = parts;
+            next_.store(0);
+            left_ = parts;
+            generation_++;
+        }
+        wake_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return left_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    RowWorkers() {
+        unsigned threads = std::thread::hardware_concurrency();
+        threads = threads > 16 ? 16 : threads;
+        try {
+            for (unsigned t = 1; t < threads; t++) workers_.emplace_back([this] { loop(); });
+        } catch (...) {
+            // no more threads to be had: the callers' thread does what the missing workers would have done
+        }
+    }
+    ~RowWorkers() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    void work() {
+        for (;;) {
+            const unsigned part = next_.fetch_add(1);
+            if (part >= parts_) return;
+            const uint32_t y0 = (uint32_t)((uint64_t)height_ * part / parts_);
+            const uint32_t y1 = (uint32_t)((uint64_t)height_ * (part + 1) / parts_);
+            (*job_)(y0, y1);
+            std::lock_guard<std::mutex> g(m_);
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                wake_.wait(g, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, job_lock_;
+    std::condition_variable wake_, done_;
+    const std::function<void(uint32_t, uint32_t)> *job_ = nullptr;
+    uint32_t height_ = 0;
+    unsigned parts_ = 0, left_ = 0;
+    std::atomic<unsigned> next_{0};
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+} // namespace
+
 template <class F> static void over_rows(uint32_t height, size_t work_per_row, F f) {
-    unsigned threads = std::thread::hardware_concurrency();
-    threads = threads > 16 ? 16 : threads;
-    if (threads < 2 || (size_t)height * work_per_row < (1u << 16) || height < threads) {
+    if ((size_t)height * work_per_row < (1u << 16) || height < 2) {
         f(0u, height);
         return;
     }
-    std::vector<std::thread> pool;
-    uint32_t done = 0;
-    try {
-        pool.reserve(threads - 1);
-        for (unsigned t = 0; t + 1 < threads; t++) {
-            const uint32_t end = (uint32_t)((uint64_t)height * (t + 1) / threads);
-            pool.emplace_back(f, done, end);
-            done = end;
-        }
-    } catch (...) {
-        // no more threads to be had: the rest runs here
+    RowWorkers &pool = RowWorkers::get();
+    const unsigned parts = std::min<unsigned>(pool.size(), height);
+    if (parts < 2) {
+        f(0u, height);
+        return;
     }
-    f(done, height);
-    for (auto &th : pool) th.join();
+    pool.run(height, parts, std::function<void(uint32_t, uint32_t)>(f));
 }
 
 // The Radiance picture the reference's ImageBuilder::write_to produces through the `image` crate's HdrEncoder
