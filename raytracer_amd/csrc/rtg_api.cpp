@@ -321,7 +321,7 @@ int layout_tree(rtg_ctx *ctx, const rtg_bvh *bvh, std::vector<DevNode> &ref_node
 // and children at once -- every tree the builders make -- is stored with the children of a node side by side and the
 // root last, so that pairs of siblings start at even positions and share a 64-byte half line.  The pairs of the
 // parents in the top kThreadedTopLevels levels come first, level by level (what every ray touches sits in one
-// compact block).  Below them a binary tree is placed by 128-byte lines (threaded_pair_slots in rtg_device.hpp);
+// compact block).  Below them a binary tree is placed by 128-byte lines (PairSlots in rtg_pair_slots.hpp);
 // other trees put the groups of all deeper parents in depth-first order.  A tree with a node that has leaves and
 // children stays in pre-order (such a node goes on to its children only after its leaves, which the kernels read
 // from the full node).  The visit order is the same in every placement.

@@ -23,7 +23,7 @@
 // triangle counts.  Positions in the threaded arrays the traversal kernels read (siblings side by side in pair slots,
 // root last) come from ranks: first the pairs under the T inner nodes of the top kThreadedTopLevels levels, level by
 // level (rank by depth, then slot), then the pairs of all deeper inner nodes line by line as PairSlots
-// (rtg_device.hpp) lays them out, from the numbers of leaders of either kind before a leader in pre-order.  The
+// (rtg_pair_slots.hpp) lays them out, from the numbers of leaders of either kind before a leader in pre-order.  The
 // children of pair g sit at 2 g and 2 g + 1.  The last two kernels write the mesh slab, the reference-order node
 // array and the leaf -> source-triangle map.
 #include <hip/hip_runtime.h>
