@@ -105,22 +105,55 @@ __device__ __forceinline__ SceneHit load_hit(const rtg_hit *p) {
     h.have = v.x != RTG_NONE;
     return h;
 }
+// A workgroup's point records leave through LDS: a lane's record is 112 bytes, and written from the lane itself a
+// store instruction would touch 56 cache lines for 1 KB of data; staged, the workgroup writes its 28 KB as one
+// contiguous run, 16 bytes per lane per store.  (Falls back to direct stores when the output is not 16-byte aligned.)
+__device__ __forceinline__ void store_points(const rtg_point &pt, bool valid, rtg_point *out_points, uint64_t first,
+                                             uint64_t n, uint2 *stage) {
+    static_assert(sizeof(rtg_point) == 112, "point record is 7 x 16 B");
+    const bool aligned = ((uintptr_t)out_points & 15u) == 0;
+    if (!aligned) {
+        if (valid) out_points[first + threadIdx.x] = pt;
+        return;
+    }
+    if (valid) {
+        uint2 w[14];
+        __builtin_memcpy(w, &pt, sizeof(pt));
+#pragma unroll
+        for (int k = 0; k < 14; k++) stage[threadIdx.x * 14 + k] = w[k];
+    }
+    __syncthreads();
+    const uint64_t here = n - first < (uint64_t)kBlock ? n - first : (uint64_t)kBlock;
+    const uint4 *src = reinterpret_cast<const uint4 *>(stage);
+    uint4 *dst = reinterpret_cast<uint4 *>(out_points + first);
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const uint32_t i = (uint32_t)k * kBlock + threadIdx.x;
+        if (i < here * 7) dst[i] = src[i];
+    }
+}
 template <bool PATCH>
 __global__ __launch_bounds__(kBlock) void k_points_primary(DevScene s, rtg_view view, uint32_t width, uint32_t height,
                                                             rtg_rect tile, const rtg_hit *__restrict__ hits,
                                                             rtg_point *out_points) {
-    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= (uint64_t)tile.w * tile.h) return;
-    uint32_t py = (uint32_t)(gid / tile.w), px = (uint32_t)(gid - (uint64_t)py * tile.w);
-    Ray ray = primary_ray(view, tile.x0 + px, tile.y0 + py, width, height);
-    scene_point<PATCH>(s, ray, load_hit(hits + gid), out_points[gid]);
+    __shared__ __align__(16) uint2 stage[kBlock * 14];
+    const uint64_t n = (uint64_t)tile.w * tile.h, first = (uint64_t)blockIdx.x * kBlock, gid = first + threadIdx.x;
+    rtg_point pt;
+    if (gid < n) {
+        uint32_t py = (uint32_t)(gid / tile.w), px = (uint32_t)(gid - (uint64_t)py * tile.w);
+        Ray ray = primary_ray(view, tile.x0 + px, tile.y0 + py, width, height);
+        scene_point<PATCH>(s, ray, load_hit(hits + gid), pt);
+    }
+    store_points(pt, gid < n, out_points, first, n, stage);
 }
 template <bool PATCH>
 __global__ __launch_bounds__(kBlock) void k_points_batch(DevScene s, const double *__restrict__ rays6, uint64_t n,
                                                           const rtg_hit *__restrict__ hits, rtg_point *out_points) {
-    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= n) return;
-    scene_point<PATCH>(s, load_ray(rays6, gid), load_hit(hits + gid), out_points[gid]);
+    __shared__ __align__(16) uint2 stage[kBlock * 14];
+    const uint64_t first = (uint64_t)blockIdx.x * kBlock, gid = first + threadIdx.x;
+    rtg_point pt;
+    if (gid < n) scene_point<PATCH>(s, load_ray(rays6, gid), load_hit(hits + gid), pt);
+    store_points(pt, gid < n, out_points, first, n, stage);
 }
 
 // compute_direct_irrad x diffuse for already-built points (renderer.rs:184-205,270-277).
