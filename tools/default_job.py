@@ -43,6 +43,23 @@ r = np.median(np.array(rows), axis=0)
 print(f"median of {frames} frames: {1e3 * r[0]:.1f} ms per frame = {1 / r[0]:.2f} frames/s; without the directions "
       f"{1e3 * (r[0] - r[1]):.1f} ms = {1 / (r[0] - r[1]):.2f} frames/s; {2 * count / r[2] / 1e6:.1f} M photon directions/s in the photon pass")
 
+# The job as a sequence: frame f's images are encoded on a host thread while the GPU renders frame f + 1 (frames are
+# independent in the reference too: src/lib.rs renders them from a parallel iterator).
+from concurrent.futures import ThreadPoolExecutor  # noqa: E402
+with ThreadPoolExecutor(1) as pool:
+    t0 = time.perf_counter()
+    pending = None
+    sizes = []
+    for frame in range(frames):
+        rgb, _, (_, _, s_pixels) = rtg.render_scene_builder_photons(ctx, frame, W, H, count, seed=frame + 1, photons_on_host=ON_HOST)
+        if pending is not None:
+            sizes.append(len(pending.result()))
+        pending = pool.submit(rtg.images_tar, rgb, W, H, s_pixels)
+    sizes.append(len(pending.result()))
+    seq = time.perf_counter() - t0
+print(f"{frames} frames as a sequence, images encoded while the next frame renders: {1e3 * seq / frames:.1f} ms per frame = "
+      f"{frames / seq:.2f} frames/s ({sum(sizes)} B of images)")
+
 if oracle_count:
     import orc  # noqa: E402
     import scenes  # noqa: E402
